@@ -1,0 +1,187 @@
+"""Generate ``tests/golden/*.npz`` by running the REFERENCE's own modules on CPU.
+
+Runs only in the build container (needs ``/root/reference``); the GPU box only sees the
+committed fixtures.  Nothing from the reference is copied: its modules are imported from
+where they lie, evaluated on deterministic inputs/weights (``tests/golden_util.py``), and only
+the resulting arrays are stored.
+
+``timm`` and ``monai`` are not installed here.  The reference's backbones use four timm names
+(``DropPath``, ``to_3tuple``, ``trunc_normal_``, ``to_2tuple``) for which the reference vendors its
+own copies under ``models/layers``; an in-memory ``timm.models.layers`` module maps to those.
+``monai.utils.ensure_tuple_rep`` is a pure tuple helper; the MONAI block classes named by the
+imports are never instantiated on this path and get inert placeholders.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+from tests.golden_util import det_fill_, det_tensor  # noqa: E402
+
+
+def _install_import_shims():
+    sys.path.insert(0, REF)
+    from models.layers.drop_path import DropPath
+    from models.layers.weight_init import trunc_normal_
+
+    def _ntuple(n):
+        def f(x):
+            return tuple(x) if isinstance(x, (tuple, list)) else (x,) * n
+        return f
+
+    timm = types.ModuleType("timm")
+    tm = types.ModuleType("timm.models")
+    tl = types.ModuleType("timm.models.layers")
+    tl.DropPath, tl.trunc_normal_ = DropPath, trunc_normal_
+    tl.to_2tuple, tl.to_3tuple = _ntuple(2), _ntuple(3)
+    timm.models, tm.layers = tm, tl
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl})
+
+    def ensure_tuple_rep(tup, dim):
+        if isinstance(tup, (tuple, list)):
+            if len(tup) != dim:
+                raise ValueError("bad length")
+            return tuple(tup)
+        return (tup,) * dim
+
+    class _Inert:  # named by imports, never instantiated on this path
+        def __getitem__(self, k):
+            raise RuntimeError("inert placeholder")
+
+    names = ["monai", "monai.utils", "monai.networks", "monai.networks.layers", "monai.networks.blocks",
+             "monai.networks.blocks.unetr_block"]
+    mods = {n: types.ModuleType(n) for n in names}
+    mods["monai.utils"].ensure_tuple_rep = ensure_tuple_rep
+    mods["monai.networks.layers"].Conv = _Inert()
+    mods["monai.networks.blocks.unetr_block"].UnetrBasicBlock = _Inert
+    sys.modules.update(mods)
+
+
+def _save(name, **arrays):
+    out = os.path.join(REPO, "tests", "golden", name)
+    np.savez_compressed(out, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                for k, v in arrays.items()})
+    print("wrote", out, {k: tuple(v.shape) for k, v in arrays.items()})
+
+
+def gen_window_attention(ref):
+    for tag, dim, ws, heads, nwin in [("h3w6", 48, 6, 3, 8), ("h24w3", 384, 3, 24, 8)]:
+        torch.manual_seed(0)
+        m = ref.WindowAttention(dim, window_size=(ws,) * 3, num_heads=heads, qkv_bias=True)
+        det_fill_(m, "attn_" + tag)
+        N = ws ** 3
+        x = det_tensor("attn_x_" + tag, (nwin, N, dim)).requires_grad_(True)
+        r = det_tensor("attn_r_" + tag, (nwin, N, dim))
+        # a region mask like BasicLayer's: windows of a (2ws)^3 volume, shift ws//2
+        from oracle.swin import shift_region_mask
+        mask = shift_region_mask(2 * ws, 2 * ws, 2 * ws, ws, ws // 2)
+        res = {}
+        for mk, msk in (("nomask", None), ("mask", mask)):
+            y, _ = m(x, mask=msk)
+            g, = torch.autograd.grad((y * r).sum(), x)
+            pg = torch.autograd.grad((m(x, mask=msk)[0] * r).sum(),
+                                     [m.qkv.weight, m.relative_position_bias_table])
+            res.update({f"y_{mk}": y, f"dx_{mk}": g, f"dtable_{mk}": pg[1]})
+            if dim <= 48:
+                res[f"dqkvw_{mk}"] = pg[0]
+        _save(f"swin_attn_{tag}.npz", **res)
+
+
+def gen_block(ref):
+    dim, heads, ws, res = 48, 3, 6, (12, 12, 12)
+    # the layer's shifted-window mask, as BasicLayer.forward builds it
+    from oracle.swin import shift_region_mask
+    mask = shift_region_mask(12, 12, 12, ws, ws // 2)
+    out = {}
+    for shift in (0, 3):
+        m = ref.SwinTransformerBlock(dim, res, heads, window_size=ws, shift_size=shift, drop_path=0.0)
+        det_fill_(m, "blk")
+        x = det_tensor("blk_x", (2, 12 ** 3, dim)).requires_grad_(True)
+        r = det_tensor("blk_r", (2, 12 ** 3, dim))
+        y, _ = m(x, mask)
+        g, = torch.autograd.grad((y * r).sum(), x)
+        out[f"y_shift{shift}"] = y
+        if shift:
+            out[f"dx_shift{shift}"] = g
+    _save("swin_block.npz", **out)
+
+
+def gen_basic_layer_mask(ref):
+    """Capture the mask BasicLayer.forward builds by intercepting the first block."""
+    layer = ref.BasicLayer(dim=48, input_resolution=(10, 12, 12), depth=2, num_heads=3, window_size=6,
+                           drop_path=0.0, downsample=ref.PatchMerging)
+    seen = {}
+    orig = layer.blocks[0].forward
+
+    def spy(x, mask_matrix, **kw):
+        seen["mask"] = mask_matrix.clone()
+        return orig(x, mask_matrix, **kw)
+    layer.blocks[0].forward = spy
+    det_fill_(layer, "layer")
+    x = det_tensor("layer_x", (1, 10 * 12 * 12, 48))
+    xo, S, H, W, xd, Ws, Wh, Ww, _ = layer(x, 10, 12, 12)
+    _save("swin_layer.npz", mask=seen["mask"].to(torch.int8), x_out=xo, x_down=xd, dims=np.array([S, H, W, Ws, Wh, Ww]))
+
+
+def gen_encoder(ref):
+    for tag, vol in (("v24", (24, 24, 24)), ("v20", (20, 20, 20))):
+        m = ref.SwinTransformerNNFormer(pretrain_img_size=vol, patch_size=(2, 2, 2), in_chans=1, embed_dim=32,
+                                        depths=[2, 2], num_heads=[2, 4], window_size=[6, 3],
+                                        drop_path_rate=0.0)
+        m.eval()
+        det_fill_(m, "enc")
+        x = det_tensor("enc_x_" + tag, (2, 1) + vol).requires_grad_(True)
+        outs = m((x, None, None))
+        loss = sum((o * det_tensor(f"enc_r{i}_" + tag, o.shape)).sum() for i, o in enumerate(outs))
+        loss.backward()
+        gw = m.layers[0].blocks[1].attn.qkv.weight.grad
+        gt = m.layers[0].blocks[1].attn.relative_position_bias_table.grad
+        gm = m.layers[1].downsample.reduction.weight.grad
+        _save(f"swin_encoder_{tag}.npz", dx=x.grad, d_qkv_w=gw, d_table=gt, d_merge_w=gm[:8],
+              **{f"out{i}": o for i, o in enumerate(outs)})
+
+
+def gen_lr_and_misc():
+    from models.optimizers.lr_scheduler import LinearWarmupCosineAnnealingLR
+    import utils.misc as misc
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=4e-4)
+    sch = LinearWarmupCosineAnnealingLR(opt, warmup_epochs=40, max_epochs=200)
+    lrs = []
+    for _ in range(200):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    aff = det_tensor("aff", (3, 4, 4))
+    t = {"orig_size": [torch.tensor([100., 120.]), torch.tensor([110., 90.]), torch.tensor([64., 80.])],
+         "extra_info": {"center": [torch.tensor([10., 30.]), torch.tensor([55., 45.]), torch.tensor([32., 8.])]}}
+    _save("lr_misc.npz", lrs=np.array(lrs, dtype=np.float64), aff_in=aff, aff_xyz=misc.get_affine_xyz(aff),
+          rel_crop=misc.get_rel_crop_loc(t))
+    vol = (np.arange(5 * 6 * 7) % 4).reshape(5, 6, 7).astype(np.uint8)
+    _save("resample.npz", vol=vol, out=misc.resample_3d(vol, (9, 6, 11)))
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("needs /root/reference (build container only)")
+    torch.set_num_threads(8)
+    _install_import_shims()
+    import models.backbones.swin_nnformer as ref
+    gen_window_attention(ref)
+    gen_block(ref)
+    gen_basic_layer_mask(ref)
+    gen_encoder(ref)
+    gen_lr_and_misc()
+
+
+if __name__ == "__main__":
+    main()
