@@ -1,0 +1,183 @@
+/* msseg.h -- C ABI of libmsseg_hip.so: the MI355X (gfx950) kernels behind the 3-D segmentation
+ * hot path (UNet / Swin-UNETR forward+backward, Dice+CE loss, sliding-window blend).
+ *
+ * The reference (zouyunkai/MedicalSemSeg) has no FFI layer: its hot path is torch/ATen + MONAI calls
+ * issued from Python.  Each entry point below names the reference call site(s) whose arithmetic it
+ * replaces (paths relative to /root/reference).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - All tensors are dense "channels-last" volumes [N, D, H, W, C]; `ld*` is the element distance
+ *    between consecutive voxels (>= C), so a kernel can read/write a channel slice of a wider
+ *    (concatenated) buffer.  Pointers must be 16-byte aligned and ld*sizeof(elem) a multiple of 16.
+ *  - dtype: MSSEG_F32 (exact fp32 MFMA path, used for parity) or MSSEG_BF16 (bf16 storage, fp32
+ *    accumulate).  Reductions, statistics, weight gradients and losses are always fp32.
+ *  - Every call only ENQUEUES work on `stream` (a hipStream_t); it never allocates, frees, syncs or
+ *    keeps caller pointers.  Scratch comes from the caller (`workspace`), sized by the *_workspace_bytes
+ *    queries.  Safe to capture into a hipGraph.
+ *  - Return value: MSSEG_OK or a negative MSSEG_E* code; msseg_last_error() gives a thread-local message.
+ */
+#ifndef MSSEG_H_
+#define MSSEG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSSEG_ABI_VERSION 1
+
+#define MSSEG_OK 0
+#define MSSEG_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MSSEG_ELAUNCH (-2)  /* HIP launch error */
+#define MSSEG_EWORKSPACE (-3) /* workspace too small */
+
+#define MSSEG_F32 0
+#define MSSEG_BF16 1
+
+typedef void* msseg_stream_t; /* hipStream_t */
+
+int msseg_abi_version(void);
+const char* msseg_last_error(void);
+/* number of compute units of the current device (grid sizing of the persistent kernels) */
+int msseg_num_cus(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight packing.  Source: fp32 parameter in torch layout.  Destination: the MFMA operand image
+ * [cout_block][k_block][tap][quarter][cout_in_block][16 bytes] consumed by the igemm kernels.
+ * Logical matrix W[m][t][k], m = m1*M0+m0, k = k1*K0+k0, read from
+ *   src[m1*s_m1 + m0*s_m0 + t'*s_t + k1*s_k1 + k0*s_k0],  t' = flip ? T-1-t : t.
+ * ------------------------------------------------------------------------------------------- */
+size_t msseg_packed_weight_bytes(int M, int T, int K, int cout_block, int dtype);
+int msseg_pack_weights(const float* src, void* dst, int dtype, int M, int M0, int T, int K, int K0,
+                       long long s_m1, long long s_m0, long long s_t, long long s_k1, long long s_k0,
+                       int flip, int cout_block, msseg_stream_t stream);
+/* cout block (16/32/48) the igemm kernels use for a layer with M logical output channels */
+int msseg_cout_block(int M);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolutions (forward-shaped).  y = conv(x, W) + bias.
+ * ------------------------------------------------------------------------------------------- */
+/* Conv3d k=3 s=1 p=1.  Replaces nn.Conv3d 3x3x3 inside MONAI UnetResBlock / BasicUNet TwoConv
+ * (models/segmentors/swin_unetr.py:73-128) and, with dgrad-packed weights, its input gradient.
+ * Requires Cin % (16/sizeof(elem)) == 0. */
+int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                        int N, int D, int H, int W, int Cin, int Cout, int dtype, msseg_stream_t stream);
+/* Conv3d k=1 (UnetResBlock.conv3, UnetOutBlock models/segmentors/swin_unetr.py:130, BasicUNet final_conv). */
+int msseg_conv3d_k1_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                        long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
+/* Conv3d with few input channels (Cin*k^3 <= 128), kernel k, stride s, pad p, gathered im2col-style:
+ * the 1->C stem convs and PatchEmbed3D.proj (models/blocks/patch_embeddings.py:109). */
+int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                            int N, int ID, int IH, int IW, int Cin, int Cout, int k, int s, int p, int dtype,
+                            msseg_stream_t stream);
+/* ConvTranspose3d k=s=2 (UnetrUpBlock.transp_conv, BasicUNet UpCat): x [N,D,H,W,Cin] -> y [N,2D,2H,2W,Cout]. */
+int msseg_deconv_k2s2_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                          int N, int D, int H, int W, int Cin, int Cout, int dtype, msseg_stream_t stream);
+/* input gradient of the above: dy [N,2D,2H,2W,Cout] -> dx [N,D,H,W,Cin]. */
+int msseg_deconv_k2s2_bwd_data(const void* dy, long long lddy, const void* wp, void* dx, long long lddx,
+                               int N, int D, int H, int W, int Cin, int Cout, int dtype, msseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight gradients (fp32 output in the torch parameter layout; deterministic two-stage reduction).
+ * `accumulate` != 0 adds into dw instead of overwriting.
+ * ------------------------------------------------------------------------------------------- */
+size_t msseg_wgrad_workspace_bytes(int M, int T, int K);
+int msseg_conv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw,
+                          int N, int D, int H, int W, int Cin, int Cout, int accumulate,
+                          void* workspace, size_t workspace_bytes, int dtype, msseg_stream_t stream);
+int msseg_conv3d_k1_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw,
+                          long long NV, int Cin, int Cout, int accumulate,
+                          void* workspace, size_t workspace_bytes, int dtype, msseg_stream_t stream);
+int msseg_conv3d_gather_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw,
+                              int N, int ID, int IH, int IW, int Cin, int Cout, int k, int s, int p, int accumulate,
+                              void* workspace, size_t workspace_bytes, int dtype, msseg_stream_t stream);
+int msseg_deconv_k2s2_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw,
+                            int N, int D, int H, int W, int Cin, int Cout, int accumulate,
+                            void* workspace, size_t workspace_bytes, int dtype, msseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Normalisation / activation / pooling / layout (HBM-bound, one pass each).
+ * ------------------------------------------------------------------------------------------- */
+/* stats[n][c][0..1] += (sum, sum of squares) over the S voxels of sample n (caller zero-fills). */
+int msseg_channel_stats(const void* x, long long ldx, float* stats, int N, long long S, int C, int dtype,
+                        msseg_stream_t stream);
+/* InstanceNorm3d(eps) [+affine] [+residual] + LeakyReLU(slope) in one pass (slope 1.0 = identity):
+ * y = lrelu((x-mean)*rstd*gamma+beta + residual).  nn.InstanceNorm3d + nn.LeakyReLU of UnetResBlock /
+ * TwoConv. */
+int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
+                           const void* residual, long long ldr, void* y, long long ldy, int N, long long S, int C,
+                           float eps, float slope, int dtype, msseg_stream_t stream);
+/* backward, pass 1: red[n][c] += (sum dz, sum dz*xhat), dz = dy * lrelu'(y) (sign taken from the output y). */
+int msseg_instnorm_act_bwd_reduce(const void* x, long long ldx, const float* stats, const void* y, long long ldy,
+                                  const void* dy, long long lddy, float* red, int N, long long S, int C, float eps,
+                                  float slope, int dtype, msseg_stream_t stream);
+/* backward, pass 2: dx = rstd*gamma*(dz - red0/S - xhat*red1/S); dres (optional) = dz. */
+int msseg_instnorm_act_bwd_apply(const void* x, long long ldx, const float* stats, const float* gamma, const void* y,
+                                 long long ldy, const void* dy, long long lddy, const float* red, void* dx,
+                                 long long lddx, void* dres, long long lddres, int N, long long S, int C, float eps,
+                                 float slope, int dtype, msseg_stream_t stream);
+/* MaxPool3d(2) forward / backward (first maximum in scan order receives the gradient, as ATen). */
+int msseg_maxpool2_fwd(const void* x, long long ldx, void* y, long long ldy, int N, int D, int H, int W, int C,
+                       int dtype, msseg_stream_t stream);
+int msseg_maxpool2_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
+                       int N, int D, int H, int W, int C, int accumulate, int dtype, msseg_stream_t stream);
+/* NCDHW (src_dtype) <-> NDHWC (dst_dtype) */
+int msseg_ncdhw_to_ndhwc(const void* src, int src_dtype, void* dst, long long ldd, int dst_dtype, int N, int C,
+                         long long S, msseg_stream_t stream);
+int msseg_ndhwc_to_ncdhw(const void* src, long long lds, int src_dtype, void* dst, int dst_dtype, int N, int C,
+                         long long S, msseg_stream_t stream);
+/* out[c] (+)= sum over rows of x[row][c] (bias gradients). */
+int msseg_channel_sum(const void* x, long long ldx, float* out, long long rows, int C, int accumulate, int dtype,
+                      msseg_stream_t stream);
+/* y = a + b (elementwise over rows x C with strides) */
+int msseg_add(const void* a, long long lda, const void* b, long long ldb, void* y, long long ldy, long long rows,
+              int C, int dtype, msseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dice + cross-entropy loss (MONAI DiceCELoss(to_onehot_y, softmax, squared_pred) as built at
+ * run_training.py:103-105, called engine/train.py:62) and the hard Dice metric (engine/train.py:89-111).
+ * logits: channels-last [N, S, ld] with ld >= C the voxel stride, or NCDHW when ld == 0; labels: one value
+ * per voxel; C <= 16.
+ * ------------------------------------------------------------------------------------------- */
+/* partial[n][c][0..3] += (sum p*t, sum p^2, sum t, -sum t*log p); hard[n][c][0..2] += (|P&T|, |P|, |T|)
+ * (either pointer may be NULL).  label_dtype: 0 = f32, 1 = bf16, 2 = u8, 3 = i64. */
+int msseg_dice_ce_partials(const void* logits, long long ld, int dtype, const void* labels, int label_dtype,
+                           float* partial, float* hard, int N, long long S, int C, msseg_stream_t stream);
+/* loss[0] = mean_{n,c}(1 - (2I+snr)/(den+sdr)) + CE ; loss[1] = dice term, loss[2] = ce term. */
+int msseg_dice_ce_finalize(const float* partial, float* loss, int N, long long S, int C, float smooth_nr,
+                           float smooth_dr, msseg_stream_t stream);
+/* dlogits = gscale[0] * dLoss/dlogits (same layout/dtype as logits). */
+int msseg_dice_ce_bwd(const void* logits, long long ld, int dtype, const void* labels, int label_dtype,
+                      const float* partial, const float* gscale, void* dlogits, long long ldd, int N, long long S,
+                      int C, float smooth_nr, float smooth_dr, msseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser: fused AdamW over one flat fp32 buffer (torch.optim.AdamW(betas=(0.9,0.95), eps=1e-6) of
+ * run_training.py:92-93; decay applies where decay_mask[i] != 0 -- timm add_weight_decay semantics).
+ * grad_scale[0] multiplies the gradient first (clip coefficient / loss-scale inverse).
+ * ------------------------------------------------------------------------------------------- */
+int msseg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
+                     long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                     const float* grad_scale, msseg_stream_t stream);
+/* out[0] = sum of squares of x[0..n) (caller zero-fills out). */
+int msseg_sumsq(const float* x, long long n, float* out, msseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sliding-window inference (engine/utils.py:120-151): gather windows, weighted blend, normalise.
+ * ------------------------------------------------------------------------------------------- */
+/* out[c][vol] += imp[roi] * win[c][roi] placed at start (z,y,x); cnt[vol] += imp (one channel).
+ * win: channels-last [roi][ld] when ld > 0, NCDHW when ld == 0. */
+int msseg_sw_blend(const void* win, long long ld, int dtype, const float* imp, float* out, float* cnt,
+                   int C, int VD, int VH, int VW, int RD, int RH, int RW, int z0, int y0, int x0,
+                   msseg_stream_t stream);
+/* win[c][roi] (NCDHW, dtype) = vol[c][window at (z0,y0,x0)] with `cval` outside the volume. */
+int msseg_sw_gather(const float* vol, void* win, int dtype, int C, int VD, int VH, int VW, int RD, int RH, int RW,
+                    int z0, int y0, int x0, float cval, msseg_stream_t stream);
+int msseg_sw_normalize(float* out, const float* cnt, int C, long long V, msseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSSEG_H_ */

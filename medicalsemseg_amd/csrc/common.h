@@ -1,0 +1,77 @@
+// Common device helpers for the msseg HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/msseg.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define MSSEG_DEVFN __device__ __forceinline__
+
+// ---- error plumbing -------------------------------------------------------------
+void msseg_set_error(const char* fmt, ...);
+#define MSSEG_FAIL(code, ...)           \
+    do {                                \
+        msseg_set_error(__VA_ARGS__);   \
+        return (code);                  \
+    } while (0)
+#define MSSEG_CHECK_LAUNCH(name)                                              \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess) MSSEG_FAIL(MSSEG_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- per-dtype traits -------------------------------------------------------------
+// A "chunk" is 16 bytes of consecutive channels: 8 bf16 or 4 f32.  One MFMA k-group
+// (4 lane-quarters x 1 chunk) therefore spans CB = 4*EPC channels: 32 (bf16) / 16 (f32).
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int EPC = 4;
+    static constexpr int CODE = MSSEG_F32;
+    static MSSEG_DEVFN float ld(const float* p) { return *p; }
+    static MSSEG_DEVFN void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+    static constexpr int EPC = 8;
+    static constexpr int CODE = MSSEG_BF16;
+    static MSSEG_DEVFN float ld(const bf16_t* p) { return (float)*p; }
+    static MSSEG_DEVFN void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+// D[row = A-row (l>>4)*4+reg][col = B-col l&15] += A[row][k] * B[k][col] over one 16-byte chunk
+// per lane-quarter: 32 k (bf16, one 16x16x32 MFMA) or 16 k (f32, four 16x16x4 MFMAs whose
+// k-order is permuted identically on both operands).
+template <typename T> MSSEG_DEVFN void mma_chunk(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b);
+template <> MSSEG_DEVFN void mma_chunk<bf16_t>(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                  acc, 0, 0, 0);
+}
+template <> MSSEG_DEVFN void mma_chunk<float>(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    f32x4_t af = __builtin_bit_cast(f32x4_t, a), bf = __builtin_bit_cast(f32x4_t, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc, 0, 0, 0);
+}
+
+// store 4 consecutive channel values
+template <typename T> MSSEG_DEVFN void store4(T* p, const f32x4_t& v);
+template <> MSSEG_DEVFN void store4<float>(float* p, const f32x4_t& v) { *(f32x4_t*)p = v; }
+template <> MSSEG_DEVFN void store4<bf16_t>(bf16_t* p, const f32x4_t& v) {
+    bf16x4_t o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *(bf16x4_t*)p = o;
+}
+
+MSSEG_DEVFN float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

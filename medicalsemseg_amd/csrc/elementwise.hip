@@ -1,0 +1,711 @@
+// HBM-bound passes: statistics, InstanceNorm+LeakyReLU (fwd/bwd), MaxPool3d(2), layout changes, channel sums,
+// weight packing, AdamW.  All tensors channels-last with an explicit voxel stride; 16-byte vector accesses when
+// the channel count allows (C % (16/sizeof(T)) == 0), scalar fallback otherwise.
+#include "common.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------------------------
+// error plumbing / device info
+// ---------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void msseg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+int msseg_abi_version(void) { return MSSEG_ABI_VERSION; }
+const char* msseg_last_error(void) { return g_err; }
+int msseg_num_cus(void) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+}
+
+namespace {
+
+template <typename T> struct Chunk {
+    static constexpr int EPC = DT<T>::EPC;
+    float v[EPC];
+    MSSEG_DEVFN void load(const T* p) {
+        if constexpr (sizeof(T) == 4) {
+            f32x4_t t = *(const f32x4_t*)p;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = t[e];
+        } else {
+            bf16x8_t t = *(const bf16x8_t*)p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+        }
+    }
+    MSSEG_DEVFN void store(T* p) const {
+        if constexpr (sizeof(T) == 4) {
+            f32x4_t t = {v[0], v[1], v[2], v[3]};
+            *(f32x4_t*)p = t;
+        } else {
+            bf16x8_t t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+            *(bf16x8_t*)p = t;
+        }
+    }
+};
+
+inline bool vec_ok(const void* p, long long ld, int C, int esz) {
+    const int epc = 16 / esz;
+    return (C % epc) == 0 && (ld % epc) == 0 && (((uintptr_t)p) & 15) == 0;
+}
+
+// Work decomposition shared by the per-(n, voxel, channel-group) passes: a block owns `rows_per_block`
+// consecutive voxels of sample blockIdx.y; thread -> (row lane, channel group); channel group fixed per thread.
+struct RowMap {
+    int groups;       // channel groups per voxel
+    int rows_par;     // voxel rows processed in parallel by a block
+};
+inline RowMap row_map(int C, int width) {
+    RowMap m;
+    m.groups = ceil_div(C, width);
+    if (m.groups > 256) m.groups = 256;
+    m.rows_par = 256 / m.groups;
+    if (m.rows_par < 1) m.rows_par = 1;
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// channel statistics: stats[n][c][0..1] += (sum x, sum x^2)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, long long ldx, float* stats,
+                                                            long long S, int C, int groups, int rows_par,
+                                                            long long rows_per_block, int nacc) {
+    constexpr int W = VEC ? DT<T>::EPC : 1;
+    __shared__ float red[256 * 2 * (VEC ? DT<T>::EPC : 1)];
+    const int n = blockIdx.y;
+    const int g = threadIdx.x % groups, rl = threadIdx.x / groups;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > S) r1 = S;
+    const T* xn = x + (long long)n * S * ldx;
+    for (int gg = g; gg * W < C; gg += groups) {
+        float s[W], s2[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) s[e] = s2[e] = 0.f;
+        if (rl < rows_par) {
+            for (long long r = r0 + rl; r < r1; r += rows_par) {
+                if constexpr (VEC) {
+                    Chunk<T> c;
+                    c.load(xn + r * ldx + gg * W);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) { s[e] += c.v[e]; s2[e] += c.v[e] * c.v[e]; }
+                } else {
+                    const float v = DT<T>::ld(xn + r * ldx + gg);
+                    s[0] += v; s2[0] += v * v;
+                }
+            }
+        }
+        // reduce over the rows_par threads that share channel group gg
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            red[(threadIdx.x * W + e) * 2 + 0] = s[e];
+            red[(threadIdx.x * W + e) * 2 + 1] = s2[e];
+        }
+        __syncthreads();
+        if (rl == 0) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                float a = 0.f, b = 0.f;
+                for (int k = 0; k < rows_par; ++k) {
+                    a += red[((k * groups + g) * W + e) * 2 + 0];
+                    b += red[((k * groups + g) * W + e) * 2 + 1];
+                }
+                const int c = gg * W + e;
+                if (nacc == 2) {
+                    atomicAdd(&stats[((long long)n * C + c) * 2 + 0], a);
+                    atomicAdd(&stats[((long long)n * C + c) * 2 + 1], b);
+                } else {
+                    atomicAdd(&stats[c], a);  // channel_sum mode: single accumulator per channel, n ignored
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_stats(const void* x, long long ldx, float* stats, int N, long long S, int C, int nacc, hipStream_t st) {
+    const bool vec = vec_ok(x, ldx, C, sizeof(T));
+    const RowMap m = row_map(C, vec ? DT<T>::EPC : 1);
+    long long blocks = ceil_div_ll(S, (long long)m.rows_par * 16);
+    const long long cap = (long long)msseg_num_cus() * 8 / (N > 0 ? N : 1) + 1;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const long long rpb = ceil_div_ll(S, blocks);
+    blocks = ceil_div_ll(S, rpb);
+    dim3 grid((unsigned)blocks, N);
+    if (vec)
+        hipLaunchKernelGGL((channel_stats_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x, ldx, stats, S, C,
+                           m.groups, m.rows_par, rpb, nacc);
+    else
+        hipLaunchKernelGGL((channel_stats_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x, ldx, stats, S, C,
+                           m.groups, m.rows_par, rpb, nacc);
+    MSSEG_CHECK_LAUNCH("channel_stats");
+    return MSSEG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// InstanceNorm + LeakyReLU
+// ---------------------------------------------------------------------------------------------------------
+struct NormParams {
+    const void* x; long long ldx;
+    const float* stats; const float* gamma; const float* beta;
+    const void* res; long long ldr;
+    void* y; long long ldy;
+    const void* dy; long long lddy;
+    float* red;
+    void* dx; long long lddx;
+    void* dres; long long lddres;
+    long long S; int C; float eps, slope;
+    long long rows_per_block; int groups, rows_par;
+};
+
+MSSEG_DEVFN void mean_rstd(const float* stats, int n, int C, int c, long long S, float eps, float& mean, float& rstd) {
+    const float inv = 1.0f / (float)S;
+    const float s = stats[((long long)n * C + c) * 2 + 0], s2 = stats[((long long)n * C + c) * 2 + 1];
+    mean = s * inv;
+    float var = s2 * inv - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    rstd = rsqrtf(var + eps);
+}
+
+// MODE 0: forward   MODE 1: backward reduce   MODE 2: backward apply
+template <typename T, bool VEC, int MODE>
+__global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
+    constexpr int W = VEC ? DT<T>::EPC : 1;
+    __shared__ float red[(MODE == 1) ? 256 * 2 * W : 1];
+    const int n = blockIdx.y;
+    const int g = threadIdx.x % p.groups, rl = threadIdx.x / p.groups;
+    const long long r0 = (long long)blockIdx.x * p.rows_per_block;
+    long long r1 = r0 + p.rows_per_block;
+    if (r1 > p.S) r1 = p.S;
+    const T* xn = (const T*)p.x + (long long)n * p.S * p.ldx;
+    const T* yn = (MODE != 0) ? (const T*)p.y + (long long)n * p.S * p.ldy : nullptr;
+    T* yo = (MODE == 0) ? (T*)p.y + (long long)n * p.S * p.ldy : nullptr;
+    const T* dyn = (MODE != 0) ? (const T*)p.dy + (long long)n * p.S * p.lddy : nullptr;
+    const T* resn = (MODE == 0 && p.res) ? (const T*)p.res + (long long)n * p.S * p.ldr : nullptr;
+    T* dxn = (MODE == 2) ? (T*)p.dx + (long long)n * p.S * p.lddx : nullptr;
+    T* drn = (MODE == 2 && p.dres) ? (T*)p.dres + (long long)n * p.S * p.lddres : nullptr;
+    const float invS = 1.0f / (float)p.S;
+
+    for (int gg = g; gg * W < p.C; gg += p.groups) {
+        float mean[W], rstd[W], sc[W], sh[W], k0[W], k1[W], a0[W], a1[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const int c = gg * W + e;
+            mean_rstd(p.stats, n, p.C, c, p.S, p.eps, mean[e], rstd[e]);
+            const float ga = p.gamma ? p.gamma[c] : 1.f;
+            sc[e] = rstd[e] * ga;
+            sh[e] = (p.beta ? p.beta[c] : 0.f) - mean[e] * sc[e];
+            a0[e] = a1[e] = 0.f;
+            if constexpr (MODE == 2) {
+                k0[e] = p.red[((long long)n * p.C + c) * 2 + 0] * invS;
+                k1[e] = p.red[((long long)n * p.C + c) * 2 + 1] * invS;
+            }
+        }
+        if (rl < p.rows_par) {
+            for (long long r = r0 + rl; r < r1; r += p.rows_par) {
+                float xv[W], o[W], yv[W], dv[W];
+                if constexpr (VEC) {
+                    Chunk<T> c; c.load(xn + r * p.ldx + gg * W);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) xv[e] = c.v[e];
+                } else {
+                    xv[0] = DT<T>::ld(xn + r * p.ldx + gg);
+                }
+                if constexpr (MODE == 0) {
+                    float rv[W];
+#pragma unroll
+                    for (int e = 0; e < W; ++e) rv[e] = 0.f;
+                    if (resn) {
+                        if constexpr (VEC) {
+                            Chunk<T> c; c.load(resn + r * p.ldr + gg * W);
+#pragma unroll
+                            for (int e = 0; e < W; ++e) rv[e] = c.v[e];
+                        } else {
+                            rv[0] = DT<T>::ld(resn + r * p.ldr + gg);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < W; ++e) {
+                        const float z = xv[e] * sc[e] + sh[e] + rv[e];
+                        o[e] = z > 0.f ? z : z * p.slope;
+                    }
+                    if constexpr (VEC) {
+                        Chunk<T> c;
+#pragma unroll
+                        for (int e = 0; e < W; ++e) c.v[e] = o[e];
+                        c.store(yo + r * p.ldy + gg * W);
+                    } else {
+                        DT<T>::st(yo + r * p.ldy + gg, o[0]);
+                    }
+                } else {
+                    if constexpr (VEC) {
+                        Chunk<T> c; c.load(yn + r * p.ldy + gg * W);
+                        Chunk<T> d; d.load(dyn + r * p.lddy + gg * W);
+#pragma unroll
+                        for (int e = 0; e < W; ++e) { yv[e] = c.v[e]; dv[e] = d.v[e]; }
+                    } else {
+                        yv[0] = DT<T>::ld(yn + r * p.ldy + gg);
+                        dv[0] = DT<T>::ld(dyn + r * p.lddy + gg);
+                    }
+#pragma unroll
+                    for (int e = 0; e < W; ++e) {
+                        const float dz = yv[e] > 0.f ? dv[e] : dv[e] * p.slope;
+                        const float xh = (xv[e] - mean[e]) * rstd[e];
+                        if constexpr (MODE == 1) {
+                            a0[e] += dz;
+                            a1[e] += dz * xh;
+                        } else {
+                            o[e] = sc[e] * (dz - k0[e] - xh * k1[e]);
+                            dv[e] = dz;
+                        }
+                    }
+                    if constexpr (MODE == 2) {
+                        if constexpr (VEC) {
+                            Chunk<T> c;
+#pragma unroll
+                            for (int e = 0; e < W; ++e) c.v[e] = o[e];
+                            c.store(dxn + r * p.lddx + gg * W);
+                            if (drn) {
+#pragma unroll
+                                for (int e = 0; e < W; ++e) c.v[e] = dv[e];
+                                c.store(drn + r * p.lddres + gg * W);
+                            }
+                        } else {
+                            DT<T>::st(dxn + r * p.lddx + gg, o[0]);
+                            if (drn) DT<T>::st(drn + r * p.lddres + gg, dv[0]);
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (MODE == 1) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                red[(threadIdx.x * W + e) * 2 + 0] = a0[e];
+                red[(threadIdx.x * W + e) * 2 + 1] = a1[e];
+            }
+            __syncthreads();
+            if (rl == 0) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    float a = 0.f, b = 0.f;
+                    for (int k = 0; k < p.rows_par; ++k) {
+                        a += red[((k * p.groups + g) * W + e) * 2 + 0];
+                        b += red[((k * p.groups + g) * W + e) * 2 + 1];
+                    }
+                    const int c = gg * W + e;
+                    atomicAdd(&p.red[((long long)n * p.C + c) * 2 + 0], a);
+                    atomicAdd(&p.red[((long long)n * p.C + c) * 2 + 1], b);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int MODE> int launch_norm(NormParams& p, int N, bool vec, hipStream_t st) {
+    const RowMap m = row_map(p.C, vec ? DT<T>::EPC : 1);
+    p.groups = m.groups; p.rows_par = m.rows_par;
+    long long blocks = ceil_div_ll(p.S, (long long)m.rows_par * 8);
+    const long long cap = (long long)msseg_num_cus() * 16 / (N > 0 ? N : 1) + 1;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    p.rows_per_block = ceil_div_ll(p.S, blocks);
+    blocks = ceil_div_ll(p.S, p.rows_per_block);
+    dim3 grid((unsigned)blocks, N);
+    if (vec) hipLaunchKernelGGL((instnorm_kernel<T, true, MODE>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((instnorm_kernel<T, false, MODE>), grid, dim3(256), 0, st, p);
+    MSSEG_CHECK_LAUNCH("instnorm");
+    return MSSEG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MaxPool3d(2)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool VEC, bool BWD>
+__global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ x, long long ldx, const T* __restrict__ dy,
+                                                       long long lddy, T* __restrict__ out, long long ldo, int N, int D,
+                                                       int H, int W, int C, int accumulate) {
+    constexpr int WD = VEC ? DT<T>::EPC : 1;
+    const int OD = D / 2, OH = H / 2, OW = W / 2;
+    const int groups = (C + WD - 1) / WD;
+    const long long total = (long long)N * OD * OH * OW * groups;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % groups);
+        long long t = i / groups;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH); t /= OH;
+        const int od = (int)(t % OD);
+        const int n = (int)(t / OD);
+        float best[WD];
+        int arg[WD];
+#pragma unroll
+        for (int e = 0; e < WD; ++e) { best[e] = -INFINITY; arg[e] = 0; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long vox = (((long long)n * D + 2 * od + (k >> 2)) * H + 2 * oh + ((k >> 1) & 1)) * W + 2 * ow + (k & 1);
+            float v[WD];
+            if constexpr (VEC) {
+                Chunk<T> c; c.load(x + vox * ldx + g * WD);
+#pragma unroll
+                for (int e = 0; e < WD; ++e) v[e] = c.v[e];
+            } else {
+                v[0] = DT<T>::ld(x + vox * ldx + g);
+            }
+#pragma unroll
+            for (int e = 0; e < WD; ++e)
+                if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; arg[e] = k; }
+        }
+        const long long ovox = (((long long)n * OD + od) * OH + oh) * OW + ow;
+        if constexpr (!BWD) {
+            if constexpr (VEC) {
+                Chunk<T> c;
+#pragma unroll
+                for (int e = 0; e < WD; ++e) c.v[e] = best[e];
+                c.store(out + ovox * ldo + g * WD);
+            } else {
+                DT<T>::st(out + ovox * ldo + g, best[0]);
+            }
+        } else {
+            float gv[WD];
+            if constexpr (VEC) {
+                Chunk<T> c; c.load(dy + ovox * lddy + g * WD);
+#pragma unroll
+                for (int e = 0; e < WD; ++e) gv[e] = c.v[e];
+            } else {
+                gv[0] = DT<T>::ld(dy + ovox * lddy + g);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const long long vox = (((long long)n * D + 2 * od + (k >> 2)) * H + 2 * oh + ((k >> 1) & 1)) * W + 2 * ow + (k & 1);
+                T* dst = out + vox * ldo + g * WD;
+                if constexpr (VEC) {
+                    Chunk<T> c;
+                    if (accumulate) c.load(dst);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < WD; ++e) c.v[e] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < WD; ++e) if (arg[e] == k) c.v[e] += gv[e];
+                    c.store(dst);
+                } else {
+                    float base = accumulate ? DT<T>::ld(dst) : 0.f;
+                    if (arg[0] == k) base += gv[0];
+                    DT<T>::st(dst, base);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// layout / misc
+// ---------------------------------------------------------------------------------------------------------
+template <typename TS, typename TD_>
+__global__ void ncdhw_to_ndhwc_kernel(const TS* __restrict__ src, TD_* __restrict__ dst, long long ldd, int N, int C,
+                                      long long S) {
+    const long long total = (long long)N * S * C;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long s = (i / C) % S;
+        const long long n = i / ((long long)C * S);
+        DT<TD_>::st(dst + (n * S + s) * ldd + c, DT<TS>::ld(src + (n * C + c) * S + s));
+    }
+}
+template <typename TS, typename TD_>
+__global__ void ndhwc_to_ncdhw_kernel(const TS* __restrict__ src, long long lds, TD_* __restrict__ dst, int N, int C,
+                                      long long S) {
+    const long long total = (long long)N * S * C;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long s = i % S;
+        const int c = (int)((i / S) % C);
+        const long long n = i / ((long long)C * S);
+        DT<TD_>::st(dst + (n * C + c) * S + s, DT<TS>::ld(src + (n * S + s) * lds + c));
+    }
+}
+
+template <typename T>
+__global__ void add_kernel(const T* a, long long lda, const T* b, long long ldb, T* y, long long ldy, long long rows,
+                           int C) {
+    const long long total = rows * C;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long r = i / C;
+        DT<T>::st(y + r * ldy + c, DT<T>::ld(a + r * lda + c) + DT<T>::ld(b + r * ldb + c));
+    }
+}
+
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict__ dst, int M, int M0, int Tt, int K,
+                                    int K0, long long s_m1, long long s_m0, long long s_t, long long s_k1,
+                                    long long s_k0, int flip, int coutb, int nkb, long long total) {
+    constexpr int EPC = DT<T>::EPC;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long t = i;
+        const int e = (int)(t % EPC); t /= EPC;
+        const int col = (int)(t % coutb); t /= coutb;
+        const int q = (int)(t % 4); t /= 4;
+        const int tap = (int)(t % Tt); t /= Tt;
+        const int kb = (int)(t % nkb);
+        const int cb = (int)(t / nkb);
+        const int m = cb * coutb + col;
+        const int k = kb * 4 * EPC + q * EPC + e;
+        float v = 0.f;
+        if (m < M && k < K) {
+            const int tt = flip ? (Tt - 1 - tap) : tap;
+            v = src[(long long)(m / M0) * s_m1 + (long long)(m % M0) * s_m0 + (long long)tt * s_t +
+                    (long long)(k / K0) * s_k1 + (long long)(k % K0) * s_k0];
+        }
+        DT<T>::st(dst + i, v);
+    }
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, const uint8_t* __restrict__ decay, long long n, float lr, float b1,
+                             float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* gscale) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * gs;
+        float pi = p[i];
+        if (!decay || decay[i]) pi *= (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+inline int grid_for(long long total, int per_thread = 4) {
+    long long b = ceil_div_ll(total, 256LL * per_thread);
+    const long long cap = (long long)msseg_num_cus() * 16;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16)                                   \
+    do {                                                                         \
+        if ((dtype) == MSSEG_F32) { CALL_F32; }                                  \
+        else if ((dtype) == MSSEG_BF16) { CALL_BF16; }                           \
+        else MSSEG_FAIL(MSSEG_EINVAL, "bad dtype %d", (int)(dtype));             \
+    } while (0)
+
+extern "C" {
+
+size_t msseg_packed_weight_bytes(int M, int T, int K, int cout_block, int dtype) {
+    const int epc = dtype == MSSEG_F32 ? 4 : 8;
+    const size_t ncb = (size_t)ceil_div(M, cout_block), nkb = (size_t)ceil_div(K, 4 * epc);
+    return ncb * nkb * (size_t)T * 4 * (size_t)cout_block * 16;
+}
+
+int msseg_pack_weights(const float* src, void* dst, int dtype, int M, int M0, int T, int K, int K0, long long s_m1,
+                       long long s_m0, long long s_t, long long s_k1, long long s_k0, int flip, int cout_block,
+                       msseg_stream_t stream) {
+    if (!src || !dst || M < 1 || T < 1 || K < 1 || M0 < 1 || K0 < 1) MSSEG_FAIL(MSSEG_EINVAL, "pack_weights: bad args");
+    if (cout_block != 16 && cout_block != 32 && cout_block != 48) MSSEG_FAIL(MSSEG_EINVAL, "pack_weights: bad cout block");
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    const long long total = (long long)(msseg_packed_weight_bytes(M, T, K, cout_block, dtype) / esz);
+    const int nkb = ceil_div(K, 64 / esz);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                  src, (float*)dst, M, M0, T, K, K0, s_m1, s_m0, s_t, s_k1, s_k0, flip, cout_block, nkb, total),
+               hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                  src, (bf16_t*)dst, M, M0, T, K, K0, s_m1, s_m0, s_t, s_k1, s_k0, flip, cout_block, nkb, total));
+    MSSEG_CHECK_LAUNCH("pack_weights");
+    return MSSEG_OK;
+}
+
+int msseg_channel_stats(const void* x, long long ldx, float* stats, int N, long long S, int C, int dtype,
+                        msseg_stream_t stream) {
+    if (!x || !stats || N < 1 || S < 1 || C < 1 || ldx < C) MSSEG_FAIL(MSSEG_EINVAL, "channel_stats: bad args");
+    DISPATCH_T(dtype, return launch_stats<float>(x, ldx, stats, N, S, C, 2, (hipStream_t)stream),
+               return launch_stats<bf16_t>(x, ldx, stats, N, S, C, 2, (hipStream_t)stream));
+}
+
+int msseg_channel_sum(const void* x, long long ldx, float* out, long long rows, int C, int accumulate, int dtype,
+                      msseg_stream_t stream) {
+    if (!x || !out || rows < 1 || C < 1 || ldx < C) MSSEG_FAIL(MSSEG_EINVAL, "channel_sum: bad args");
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, (hipStream_t)stream) != hipSuccess)
+        MSSEG_FAIL(MSSEG_ELAUNCH, "channel_sum: memset failed");
+    DISPATCH_T(dtype, return launch_stats<float>(x, ldx, out, 1, rows, C, 1, (hipStream_t)stream),
+               return launch_stats<bf16_t>(x, ldx, out, 1, rows, C, 1, (hipStream_t)stream));
+}
+
+int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
+                           const void* residual, long long ldr, void* y, long long ldy, int N, long long S, int C,
+                           float eps, float slope, int dtype, msseg_stream_t stream) {
+    if (!x || !stats || !y || N < 1 || S < 1 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_fwd: bad args");
+    NormParams p{};
+    p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = gamma; p.beta = beta; p.res = residual; p.ldr = ldr;
+    p.y = y; p.ldy = ldy; p.S = S; p.C = C; p.eps = eps; p.slope = slope;
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    const bool vec = vec_ok(x, ldx, C, esz) && vec_ok(y, ldy, C, esz) && (!residual || vec_ok(residual, ldr, C, esz));
+    DISPATCH_T(dtype, return (launch_norm<float, 0>(p, N, vec, (hipStream_t)stream)),
+               return (launch_norm<bf16_t, 0>(p, N, vec, (hipStream_t)stream)));
+}
+
+int msseg_instnorm_act_bwd_reduce(const void* x, long long ldx, const float* stats, const void* y, long long ldy,
+                                  const void* dy, long long lddy, float* red, int N, long long S, int C, float eps,
+                                  float slope, int dtype, msseg_stream_t stream) {
+    if (!x || !stats || !y || !dy || !red) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_bwd_reduce: null pointer");
+    NormParams p{};
+    p.x = x; p.ldx = ldx; p.stats = stats; p.y = (void*)y; p.ldy = ldy; p.dy = dy; p.lddy = lddy; p.red = red;
+    p.S = S; p.C = C; p.eps = eps; p.slope = slope;
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    const bool vec = vec_ok(x, ldx, C, esz) && vec_ok(y, ldy, C, esz) && vec_ok(dy, lddy, C, esz);
+    DISPATCH_T(dtype, return (launch_norm<float, 1>(p, N, vec, (hipStream_t)stream)),
+               return (launch_norm<bf16_t, 1>(p, N, vec, (hipStream_t)stream)));
+}
+
+int msseg_instnorm_act_bwd_apply(const void* x, long long ldx, const float* stats, const float* gamma, const void* y,
+                                 long long ldy, const void* dy, long long lddy, const float* red, void* dx,
+                                 long long lddx, void* dres, long long lddres, int N, long long S, int C, float eps,
+                                 float slope, int dtype, msseg_stream_t stream) {
+    if (!x || !stats || !y || !dy || !red || !dx) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_bwd_apply: null pointer");
+    NormParams p{};
+    p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = gamma; p.y = (void*)y; p.ldy = ldy; p.dy = dy; p.lddy = lddy;
+    p.red = (float*)red; p.dx = dx; p.lddx = lddx; p.dres = dres; p.lddres = lddres;
+    p.S = S; p.C = C; p.eps = eps; p.slope = slope;
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    const bool vec = vec_ok(x, ldx, C, esz) && vec_ok(y, ldy, C, esz) && vec_ok(dy, lddy, C, esz) &&
+                     vec_ok(dx, lddx, C, esz) && (!dres || vec_ok(dres, lddres, C, esz));
+    DISPATCH_T(dtype, return (launch_norm<float, 2>(p, N, vec, (hipStream_t)stream)),
+               return (launch_norm<bf16_t, 2>(p, N, vec, (hipStream_t)stream)));
+}
+
+int msseg_maxpool2_fwd(const void* x, long long ldx, void* y, long long ldy, int N, int D, int H, int W, int C,
+                       int dtype, msseg_stream_t stream) {
+    if (!x || !y || D < 2 || H < 2 || W < 2 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "maxpool2_fwd: bad args");
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    const bool vec = vec_ok(x, ldx, C, esz) && vec_ok(y, ldy, C, esz);
+    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * ceil_div(C, vec ? 16 / esz : 1);
+    const int g = grid_for(total, 1);
+#define MP_F(T_, V_) hipLaunchKernelGGL((maxpool2_kernel<T_, V_, false>), dim3(g), dim3(256), 0, (hipStream_t)stream, \
+                                        (const T_*)x, ldx, (const T_*)nullptr, 0LL, (T_*)y, ldy, N, D, H, W, C, 0)
+    DISPATCH_T(dtype, if (vec) MP_F(float, true); else MP_F(float, false),
+               if (vec) MP_F(bf16_t, true); else MP_F(bf16_t, false));
+#undef MP_F
+    MSSEG_CHECK_LAUNCH("maxpool2_fwd");
+    return MSSEG_OK;
+}
+
+int msseg_maxpool2_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int N,
+                       int D, int H, int W, int C, int accumulate, int dtype, msseg_stream_t stream) {
+    if (!x || !dy || !dx || D < 2 || H < 2 || W < 2 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "maxpool2_bwd: bad args");
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    const bool vec = vec_ok(x, ldx, C, esz) && vec_ok(dy, lddy, C, esz) && vec_ok(dx, lddx, C, esz);
+    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * ceil_div(C, vec ? 16 / esz : 1);
+    const int g = grid_for(total, 1);
+#define MP_B(T_, V_) hipLaunchKernelGGL((maxpool2_kernel<T_, V_, true>), dim3(g), dim3(256), 0, (hipStream_t)stream, \
+                                        (const T_*)x, ldx, (const T_*)dy, lddy, (T_*)dx, lddx, N, D, H, W, C, accumulate)
+    DISPATCH_T(dtype, if (vec) MP_B(float, true); else MP_B(float, false),
+               if (vec) MP_B(bf16_t, true); else MP_B(bf16_t, false));
+#undef MP_B
+    MSSEG_CHECK_LAUNCH("maxpool2_bwd");
+    return MSSEG_OK;
+}
+
+int msseg_ncdhw_to_ndhwc(const void* src, int src_dtype, void* dst, long long ldd, int dst_dtype, int N, int C,
+                         long long S, msseg_stream_t stream) {
+    if (!src || !dst || N < 1 || C < 1 || S < 1 || ldd < C) MSSEG_FAIL(MSSEG_EINVAL, "ncdhw_to_ndhwc: bad args");
+    const int g = grid_for((long long)N * C * S);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == MSSEG_F32 && dst_dtype == MSSEG_F32)
+        hipLaunchKernelGGL((ncdhw_to_ndhwc_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, ldd, N, C, S);
+    else if (src_dtype == MSSEG_F32 && dst_dtype == MSSEG_BF16)
+        hipLaunchKernelGGL((ncdhw_to_ndhwc_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, ldd, N, C, S);
+    else if (src_dtype == MSSEG_BF16 && dst_dtype == MSSEG_BF16)
+        hipLaunchKernelGGL((ncdhw_to_ndhwc_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, ldd, N, C, S);
+    else if (src_dtype == MSSEG_BF16 && dst_dtype == MSSEG_F32)
+        hipLaunchKernelGGL((ncdhw_to_ndhwc_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, ldd, N, C, S);
+    else MSSEG_FAIL(MSSEG_EINVAL, "ncdhw_to_ndhwc: bad dtypes");
+    MSSEG_CHECK_LAUNCH("ncdhw_to_ndhwc");
+    return MSSEG_OK;
+}
+
+int msseg_ndhwc_to_ncdhw(const void* src, long long lds, int src_dtype, void* dst, int dst_dtype, int N, int C,
+                         long long S, msseg_stream_t stream) {
+    if (!src || !dst || N < 1 || C < 1 || S < 1 || lds < C) MSSEG_FAIL(MSSEG_EINVAL, "ndhwc_to_ncdhw: bad args");
+    const int g = grid_for((long long)N * C * S);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == MSSEG_F32 && dst_dtype == MSSEG_F32)
+        hipLaunchKernelGGL((ndhwc_to_ncdhw_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)src, lds, (float*)dst, N, C, S);
+    else if (src_dtype == MSSEG_BF16 && dst_dtype == MSSEG_F32)
+        hipLaunchKernelGGL((ndhwc_to_ncdhw_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, lds, (float*)dst, N, C, S);
+    else if (src_dtype == MSSEG_BF16 && dst_dtype == MSSEG_BF16)
+        hipLaunchKernelGGL((ndhwc_to_ncdhw_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, lds, (bf16_t*)dst, N, C, S);
+    else if (src_dtype == MSSEG_F32 && dst_dtype == MSSEG_BF16)
+        hipLaunchKernelGGL((ndhwc_to_ncdhw_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)src, lds, (bf16_t*)dst, N, C, S);
+    else MSSEG_FAIL(MSSEG_EINVAL, "ndhwc_to_ncdhw: bad dtypes");
+    MSSEG_CHECK_LAUNCH("ndhwc_to_ncdhw");
+    return MSSEG_OK;
+}
+
+int msseg_add(const void* a, long long lda, const void* b, long long ldb, void* y, long long ldy, long long rows, int C,
+              int dtype, msseg_stream_t stream) {
+    if (!a || !b || !y || rows < 1 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "add: bad args");
+    const int g = grid_for(rows * C);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(add_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)a, lda,
+                                  (const float*)b, ldb, (float*)y, ldy, rows, C),
+               hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
+                                  (const bf16_t*)b, ldb, (bf16_t*)y, ldy, rows, C));
+    MSSEG_CHECK_LAUNCH("add");
+    return MSSEG_OK;
+}
+
+int msseg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
+                     long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                     const float* grad_scale, msseg_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) MSSEG_FAIL(MSSEG_EINVAL, "adamw_step: bad args");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, decay_mask, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    MSSEG_CHECK_LAUNCH("adamw_step");
+    return MSSEG_OK;
+}
+
+int msseg_sumsq(const float* x, long long n, float* out, msseg_stream_t stream) {
+    if (!x || !out || n < 1) MSSEG_FAIL(MSSEG_EINVAL, "sumsq: bad args");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 16)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    MSSEG_CHECK_LAUNCH("sumsq");
+    return MSSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,390 @@
+// Implicit-GEMM forward-shaped convolutions on MFMA (gfx950).
+//
+//   D[cout][voxel] = sum_{tap, c} W[cout][tap][c] * X[voxel + tap][c]
+//
+// One persistent workgroup walks output tiles.  Per tile and per block of CB = 4 chunks of input
+// channels (32 bf16 / 16 f32) it stages
+//   A: the input halo tile, channel-chunk-planar  [quarter q][halo voxel][16 B]
+//   B: the packed weights for that channel block  [tap][q][cout][16 B]   (resident across tiles when
+//      the layer has a single channel block)
+// in LDS, then every wave runs NTAPS x MT x NT MFMA k-groups with both operands read as ds_read_b128.
+// The planar A image keeps the 16 voxel rows of an MFMA operand on 16 consecutive 16-byte slots for
+// every tap shift, and plane strides are multiples of 256 B, so the reads are bank-conflict free.
+// Weights are the MFMA "A" operand (rows = cout) so that each lane ends up with 4 consecutive output
+// channels of one voxel and the epilogue stores 8 B (bf16) / 16 B (f32) per lane.
+//
+// Source modes (how the A tile is filled) and epilogues cover: conv k3 s1 p1 (+ its input gradient with
+// flipped weights), conv k1, few-channel convs gathered im2col-style (stem conv, patch embedding),
+// ConvTranspose k2 s2 forward (1x1 GEMM + pixel-shuffle scatter) and its input gradient (gather).
+#include "common.h"
+
+namespace {
+
+enum { SRC_DIRECT = 0, SRC_GATHER = 1, SRC_DECONV_BWD = 2 };
+enum { EPI_STORE = 0, EPI_DECONV = 1 };
+
+struct IgemmParams {
+    const void* x;
+    long long ldx;
+    const void* wp;
+    const float* bias;
+    void* y;
+    long long ldy;
+    int N, D, H, W;      // tiled output grid (flat mode: N = D = H = 1, W = number of output voxels)
+    int ID, IH, IW;      // source spatial dims (gather / deconv modes)
+    int OD, OH, OW;      // output spatial dims of one sample (flat modes that need coordinates)
+    int K, M, NKB;       // logical input channels, logical output channels, channel blocks
+    int tiles_d, tiles_h, tiles_w;
+    int ntiles;
+    int cin, k, s, p;    // gather: real Cin, kernel, stride, pad
+    int creal;           // deconv modes: real channel count of the fine tensor
+    int vec_store;       // y / ldy allow 4-element vector stores
+};
+
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT>
+struct IgemmCfg {
+    static constexpr int EPC = DT<T>::EPC;
+    static constexpr int CB = 4 * EPC;
+    static constexpr int PAD = (NTAPS == 27) ? 1 : 0;
+    static constexpr int PD = TD + 2 * PAD, PH = TH + 2 * PAD, PW = TW + 2 * PAD;
+    static constexpr int HV = PD * PH * PW;
+    static constexpr int TV = TD * TH * TW;
+    static constexpr int MT = TV / 16 / WAVES;
+    static constexpr int NTHREADS = WAVES * 64;
+    static constexpr int COUTB = NT * 16;
+    static constexpr int PLANE = ((HV * 16 + 255) / 256) * 256;
+    static constexpr int A_BYTES = ((4 * PLANE + 64 + 255) / 256) * 256;
+    static constexpr int B_BYTES = NTAPS * 4 * COUTB * 16;
+    static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
+    static_assert(TV % (16 * WAVES) == 0, "tile must split into 16-voxel MFMA tiles per wave");
+};
+
+MSSEG_DEVFN int aoff(int q, int plane) { return q * plane + (q >> 1) * 32; }
+
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT>
+__global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams p) {
+    using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT>;
+    constexpr int EPC = C::EPC, CB = C::CB, PAD = C::PAD, PH = C::PH, PW = C::PW, HV = C::HV, MT = C::MT;
+    constexpr int NTHREADS = C::NTHREADS, COUTB = C::COUTB, PLANE = C::PLANE;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    unsigned char* ldsA = smem;
+    unsigned char* ldsB = smem + C::A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int coutblk = blockIdx.y;
+    const T* __restrict__ xg = (const T*)p.x;
+    T* __restrict__ yg = (T*)p.y;
+
+    // per-lane LDS offsets of the voxel rows this lane feeds into the MFMA B operand
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int v = (wave * MT + m) * 16 + r;
+        const int td = v / (TH * TW), th = (v / TW) % TH, tw = v % TW;
+        abase[m] = aoff(q, PLANE) + ((td * PH + th) * PW + tw) * 16;
+    }
+    const int bbase = (q * COUTB + r) * 16;
+    int kb_loaded = -1;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+        const int th_i = t % p.tiles_h; t /= p.tiles_h;
+        const int td_i = t % p.tiles_d; t /= p.tiles_d;
+        const int n = t;
+        const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+
+        f32x4_t acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        for (int kb = 0; kb < p.NKB; ++kb) {
+            __syncthreads();
+            // ---------------- stage A ----------------
+            for (int i = tid; i < HV * 4; i += NTHREADS) {
+                const int cq = i & 3, hv = i >> 2;
+                const int c = kb * CB + cq * EPC;
+                u32x4_t val = {0u, 0u, 0u, 0u};
+                if constexpr (SRC == SRC_DIRECT) {
+                    const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
+                    const int d = d0 - PAD + hd, h = h0 - PAD + hh, w = w0 - PAD + hw;
+                    if (c < p.K && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H &&
+                        (unsigned)w < (unsigned)p.W) {
+                        const long long vox = (((long long)n * p.D + d) * p.H + h) * p.W + w;
+                        val = *(const u32x4_t*)(xg + vox * p.ldx + c);
+                    }
+                } else if constexpr (SRC == SRC_GATHER) {
+                    const int ov = w0 + hv;  // flat output voxel
+                    if (ov < p.W && c < p.K) {
+                        int tt = ov;
+                        const int ow = tt % p.OW; tt /= p.OW;
+                        const int oh = tt % p.OH; tt /= p.OH;
+                        const int od = tt % p.OD; const int nn = tt / p.OD;
+                        alignas(16) T tmp[EPC];
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            const int vc = c + e;
+                            float fv = 0.f;
+                            if (vc < p.K) {
+                                const int tap = vc / p.cin, ci = vc - tap * p.cin;
+                                const int kw = tap % p.k, kh = (tap / p.k) % p.k, kd = tap / (p.k * p.k);
+                                const int id = od * p.s - p.p + kd, ih = oh * p.s - p.p + kh, iw = ow * p.s - p.p + kw;
+                                if ((unsigned)id < (unsigned)p.ID && (unsigned)ih < (unsigned)p.IH &&
+                                    (unsigned)iw < (unsigned)p.IW) {
+                                    const long long vox = (((long long)nn * p.ID + id) * p.IH + ih) * p.IW + iw;
+                                    fv = DT<T>::ld(xg + vox * p.ldx + ci);
+                                }
+                            }
+                            DT<T>::st(&tmp[e], fv);
+                        }
+                        val = *(const u32x4_t*)tmp;
+                    }
+                } else {  // SRC_DECONV_BWD: coarse voxel gathers its 8 fine children
+                    const int cv = w0 + hv;
+                    if (cv < p.W && c < p.K) {
+                        int tt = cv;
+                        const int cw = tt % p.OW; tt /= p.OW;
+                        const int ch = tt % p.OH; tt /= p.OH;
+                        const int cd = tt % p.OD; const int nn = tt / p.OD;
+                        const int abc = c / p.creal, co = c - abc * p.creal;
+                        const int fd = 2 * cd + (abc >> 2), fh = 2 * ch + ((abc >> 1) & 1), fw = 2 * cw + (abc & 1);
+                        const long long vox = (((long long)nn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
+                        val = *(const u32x4_t*)(xg + vox * p.ldx + co);
+                    }
+                }
+                *(u32x4_t*)(ldsA + aoff(cq, PLANE) + hv * 16) = val;
+            }
+            // ---------------- stage B (skipped while the resident block is the one needed) ----------------
+            if (kb_loaded != kb) {
+                const u32x4_t* src = (const u32x4_t*)((const unsigned char*)p.wp +
+                                                      ((long long)coutblk * p.NKB + kb) * C::B_BYTES);
+                for (int i = tid; i < C::B_BYTES / 16; i += NTHREADS) ((u32x4_t*)ldsB)[i] = src[i];
+                kb_loaded = kb;
+            }
+            __syncthreads();
+            // ---------------- MFMA ----------------
+#pragma unroll
+            for (int tap = 0; tap < NTAPS; ++tap) {
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                const int toff = (NTAPS == 27) ? ((kd * PH + kh) * PW + kw) * 16 : 0;
+                u32x4_t bf[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bf[j] = *(const u32x4_t*)(ldsB + bbase + tap * (4 * COUTB * 16) + j * 256);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const u32x4_t af = *(const u32x4_t*)(ldsA + abase[m] + toff);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) mma_chunk<T>(acc[m][j], bf[j], af);
+                }
+            }
+        }
+        // ---------------- epilogue ----------------
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int v = (wave * MT + m) * 16 + r;
+            const int td = v / (TH * TW), th = (v / TW) % TH, tw = v % TW;
+            const int d = d0 + td, h = h0 + th, w = w0 + tw;
+            if (d >= p.D || h >= p.H || w >= p.W) continue;
+            long long vox;
+            int dn = 0, dd = 0, dh = 0, dw = 0;
+            if constexpr (EPI == EPI_STORE) {
+                vox = (((long long)n * p.D + d) * p.H + h) * p.W + w;
+            } else {
+                int tt = w;
+                dw = tt % p.OW; tt /= p.OW;
+                dh = tt % p.OH; tt /= p.OH;
+                dd = tt % p.OD; dn = tt / p.OD;
+                vox = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = coutblk * COUTB + j * 16 + q * 4;
+                if (co >= p.M) continue;
+                f32x4_t o = acc[m][j];
+                T* dst;
+                int cbase;
+                if constexpr (EPI == EPI_STORE) {
+                    cbase = co;
+                    dst = yg + vox * p.ldy + co;
+                } else {
+                    const int abc = co / p.creal;
+                    cbase = co - abc * p.creal;
+                    const int fd = 2 * dd + (abc >> 2), fh = 2 * dh + ((abc >> 1) & 1), fw = 2 * dw + (abc & 1);
+                    const long long fv = (((long long)dn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
+                    dst = yg + fv * p.ldy + cbase;
+                }
+                if (p.vec_store && co + 4 <= p.M) {
+                    if (p.bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += p.bias[cbase + e];
+                    }
+                    store4<T>(dst, o);
+                } else {
+                    for (int e = 0; e < 4 && co + e < p.M; ++e)
+                        DT<T>::st(dst + e, o[e] + (p.bias ? p.bias[cbase + e] : 0.f));
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT>
+int launch_cfg(IgemmParams& p, hipStream_t stream) {
+    using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT>;
+    p.tiles_d = ceil_div(p.D, TD);
+    p.tiles_h = ceil_div(p.H, TH);
+    p.tiles_w = ceil_div(p.W, TW);
+    const long long nt = (long long)p.N * p.tiles_d * p.tiles_h * p.tiles_w;
+    if (nt > 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "igemm: too many tiles");
+    p.ntiles = (int)nt;
+    p.NKB = ceil_div(p.K, C::CB);
+    p.vec_store = ((((uintptr_t)p.y) % (4 * sizeof(T))) == 0 && (p.ldy % 4) == 0) ? 1 : 0;
+    auto kern = igemm_fwd_kernel<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) !=
+            hipSuccess)
+            MSSEG_FAIL(MSSEG_ELAUNCH, "igemm: cannot set dynamic LDS size %d", C::LDS_BYTES);
+        attr_set = true;
+    }
+    const int ncb = ceil_div(p.M, C::COUTB);
+    const int wg_per_cu = (C::LDS_BYTES > 80 * 1024) ? 1 : ((C::LDS_BYTES > 40 * 1024) ? 2 : 4);
+    int gx = msseg_num_cus() * wg_per_cu / (ncb > 1 ? 1 : 1);
+    if (gx > p.ntiles) gx = p.ntiles;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, ncb, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+    MSSEG_CHECK_LAUNCH("igemm_fwd");
+    return MSSEG_OK;
+}
+
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES>
+int launch_nt(IgemmParams& p, hipStream_t stream) {
+    const int cb = msseg_cout_block(p.M);
+    switch (cb) {
+        case 16: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 1>(p, stream);
+        case 32: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 2>(p, stream);
+        case 48: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 3>(p, stream);
+    }
+    MSSEG_FAIL(MSSEG_EINVAL, "igemm: bad cout block %d", cb);
+}
+
+template <typename T> int launch_k3(IgemmParams& p, hipStream_t stream) {
+    const int mn = p.D < p.H ? (p.D < p.W ? p.D : p.W) : (p.H < p.W ? p.H : p.W);
+    if (mn >= 32) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8>(p, stream);
+    if (mn >= 12) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 4, 8, 4>(p, stream);
+    return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 2, 4, 8, 4>(p, stream);
+}
+
+template <typename T, int SRC, int EPI> int launch_flat(IgemmParams& p, hipStream_t stream) {
+    return launch_nt<T, 1, SRC, EPI, 1, 1, 256, 4>(p, stream);
+}
+
+int check_common(const void* x, long long ldx, const void* wp, const void* y, long long ldy, int dtype, int esz) {
+    if (!x || !wp || !y) MSSEG_FAIL(MSSEG_EINVAL, "igemm: null pointer");
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "igemm: bad dtype %d", dtype);
+    if (((uintptr_t)x | (uintptr_t)wp) & 15) MSSEG_FAIL(MSSEG_EINVAL, "igemm: x/wp must be 16-byte aligned");
+    if ((ldx * esz) % 16) MSSEG_FAIL(MSSEG_EINVAL, "igemm: ldx*elem must be a multiple of 16 bytes");
+    (void)ldy;
+    return MSSEG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msseg_cout_block(int M) {
+    if (M <= 16) return 16;
+    if (M % 32 == 0) return 32;
+    if (M % 48 == 0) return 48;
+    return 32;
+}
+
+int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                        int N, int D, int H, int W, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    int rc = check_common(x, ldx, wp, y, ldy, dtype, esz);
+    if (rc) return rc;
+    if (N < 1 || D < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3: bad shape");
+    if (Cin % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3: Cin=%d must be a multiple of %d (use conv3d_gather)", Cin, 16 / esz);
+    if (ldx < Cin || ldy < Cout) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3: ld smaller than channels");
+    IgemmParams p{};
+    p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.K = Cin; p.M = Cout;
+    return dtype == MSSEG_F32 ? launch_k3<float>(p, (hipStream_t)stream) : launch_k3<bf16_t>(p, (hipStream_t)stream);
+}
+
+int msseg_conv3d_k1_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                        long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    int rc = check_common(x, ldx, wp, y, ldy, dtype, esz);
+    if (rc) return rc;
+    if (NV < 1 || NV > 0x7fffffffLL || Cin < 1 || Cout < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1: bad shape");
+    if (Cin % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1: Cin=%d must be a multiple of %d", Cin, 16 / esz);
+    IgemmParams p{};
+    p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy;
+    p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = Cin; p.M = Cout;
+    return dtype == MSSEG_F32 ? launch_flat<float, SRC_DIRECT, EPI_STORE>(p, (hipStream_t)stream)
+                              : launch_flat<bf16_t, SRC_DIRECT, EPI_STORE>(p, (hipStream_t)stream);
+}
+
+int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                            int N, int ID, int IH, int IW, int Cin, int Cout, int k, int s, int pd, int dtype,
+                            msseg_stream_t stream) {
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    if (!x || !wp || !y) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: null pointer");
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: bad dtype");
+    if (k < 1 || s < 1 || pd < 0 || Cin < 1 || Cin * k * k * k > 128)
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: Cin*k^3=%d must be <= 128", Cin * k * k * k);
+    const int OD = (ID + 2 * pd - k) / s + 1, OH = (IH + 2 * pd - k) / s + 1, OW = (IW + 2 * pd - k) / s + 1;
+    if (OD < 1 || OH < 1 || OW < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: empty output");
+    const long long NV = (long long)N * OD * OH * OW;
+    if (NV > 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: too many voxels");
+    IgemmParams p{};
+    p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy;
+    p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = Cin * k * k * k; p.M = Cout;
+    p.ID = ID; p.IH = IH; p.IW = IW; p.OD = OD; p.OH = OH; p.OW = OW;
+    p.cin = Cin; p.k = k; p.s = s; p.p = pd;
+    return dtype == MSSEG_F32 ? launch_flat<float, SRC_GATHER, EPI_STORE>(p, (hipStream_t)stream)
+                              : launch_flat<bf16_t, SRC_GATHER, EPI_STORE>(p, (hipStream_t)stream);
+}
+
+int msseg_deconv_k2s2_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                          int N, int D, int H, int W, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    int rc = check_common(x, ldx, wp, y, ldy, dtype, esz);
+    if (rc) return rc;
+    if (Cin % (16 / esz) || Cout % 4) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2: Cin %% %d and Cout %% 4 must be 0", 16 / esz);
+    const long long NV = (long long)N * D * H * W;
+    if (NV < 1 || NV > 0x7fffffffLL / 8) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2: bad voxel count");
+    IgemmParams p{};
+    p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy;
+    p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = Cin; p.M = 8 * Cout;
+    p.OD = D; p.OH = H; p.OW = W; p.creal = Cout;
+    return dtype == MSSEG_F32 ? launch_flat<float, SRC_DIRECT, EPI_DECONV>(p, (hipStream_t)stream)
+                              : launch_flat<bf16_t, SRC_DIRECT, EPI_DECONV>(p, (hipStream_t)stream);
+}
+
+int msseg_deconv_k2s2_bwd_data(const void* dy, long long lddy, const void* wp, void* dx, long long lddx,
+                               int N, int D, int H, int W, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    int rc = check_common(dy, lddy, wp, dx, lddx, dtype, esz);
+    if (rc) return rc;
+    if (Cout % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_data: Cout %% %d must be 0", 16 / esz);
+    const long long NV = (long long)N * D * H * W;
+    if (NV < 1 || NV > 0x7fffffffLL / 8) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_data: bad voxel count");
+    IgemmParams p{};
+    p.x = dy; p.ldx = lddy; p.wp = wp; p.bias = nullptr; p.y = dx; p.ldy = lddx;
+    p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = 8 * Cout; p.M = Cin;
+    p.OD = D; p.OH = H; p.OW = W; p.creal = Cout;
+    return dtype == MSSEG_F32 ? launch_flat<float, SRC_DECONV_BWD, EPI_STORE>(p, (hipStream_t)stream)
+                              : launch_flat<bf16_t, SRC_DECONV_BWD, EPI_STORE>(p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,430 @@
+// Weight-gradient implicit GEMMs on MFMA (gfx950).
+//
+//   dW[m][tap][k] = sum_v P[v][m] * Q[v + tap][k]        (P = output-gradient role, Q = input role)
+//
+// The contraction index is the voxel, so both MFMA operands need "8 consecutive voxels of one channel"
+// per lane while HBM holds "all channels of one voxel".  Tiles are staged row-major [voxel][channel] in
+// LDS and read with ds_read_b64_tr_b16 (the CDNA4 transposing LDS read) for bf16; the f32 path needs one
+// element per lane and reads plain dwords.  One persistent workgroup walks voxel tiles and keeps its
+// partial dW for a (m-block, k-block) pair in registers (27 taps split over 4 waves: 7/7/7/6), then writes
+// ONE fp32 slab; a second kernel sums the slabs in a fixed order (deterministic) straight into the
+// torch-layout gradient.
+#include "common.h"
+
+namespace {
+
+enum { Q_DIRECT = 0, Q_GATHER = 1, Q_DECONV = 2 };
+
+struct WgradParams {
+    const void* pten;  // P tensor (channels M), channels-last
+    long long ldp;
+    const void* qten;  // Q tensor (channels K or source of the gathered virtual channels)
+    long long ldq;
+    float* slabs;
+    int N, D, H, W;    // tiled voxel grid of P (flat: N=D=H=1, W = voxels)
+    int ID, IH, IW;    // gather source dims
+    int OD, OH, OW;    // per-sample voxel grid dims (flat modes)
+    int M, K;          // logical channels
+    int mblks, kblks;
+    int tiles_d, tiles_h, tiles_w, ntiles;
+    int cin, k, s, p;
+    int creal;
+};
+
+template <typename T, int NTAPS, int TD, int TH, int TW> struct WgCfg {
+    static constexpr int ESZ = sizeof(T);
+    static constexpr int CBW = 64 / ESZ;       // channels per block: 32 bf16 / 16 f32
+    static constexpr int CT = CBW / 16;        // 16-wide MFMA tiles per block
+    static constexpr int PAD = (NTAPS == 27) ? 1 : 0;
+    static constexpr int PD = TD + 2 * PAD, PH = TH + 2 * PAD, PW = TW + 2 * PAD;
+    static constexpr int HV = PD * PH * PW;
+    static constexpr int TV = TD * TH * TW;
+    static constexpr int RS = 64 + (ESZ == 2 ? 32 : 0);  // LDS row stride in bytes (bf16 rows padded: tr-read banks)
+    static constexpr int P_BYTES = ((TV * RS + 255) / 256) * 256;
+    static constexpr int Q_BYTES = ((HV * RS + 255) / 256) * 256;
+    static constexpr int LDS_BYTES = P_BYTES + Q_BYTES;
+    static constexpr int WAVES = 4;
+    static constexpr int NTHREADS = 256;
+    static constexpr int TAPW = (NTAPS + WAVES - 1) / WAVES;  // taps per wave (27 -> 7)
+    static constexpr int KSTEP = (ESZ == 2) ? 32 : 4;         // voxels per MFMA k-step
+    static constexpr int NKS = TV / KSTEP;
+    static constexpr int SLAB_FLOATS = NTAPS * CBW * CBW;
+    static_assert(TV % KSTEP == 0, "tile voxels must be a multiple of the k-step");
+};
+
+MSSEG_DEVFN bf16x4_t lds_tr_read(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (__attribute__((address_space(3))) bf16x4_t*)(uintptr_t)(uint32_t)(uintptr_t)p);
+}
+
+template <typename T, int NTAPS, int QSRC, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
+    using C = WgCfg<T, NTAPS, TD, TH, TW>;
+    constexpr int CBW = C::CBW, CT = C::CT, PAD = C::PAD, PH = C::PH, PW = C::PW, HV = C::HV, TV = C::TV;
+    constexpr int RS = C::RS, TAPW = C::TAPW, NKS = C::NKS, EPC = DT<T>::EPC;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    unsigned char* ldsP = smem;
+    unsigned char* ldsQ = smem + C::P_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mblk = blockIdx.y / p.kblks, kblk = blockIdx.y % p.kblks;
+    const T* __restrict__ pg = (const T*)p.pten;
+    const T* __restrict__ qg = (const T*)p.qten;
+    const int tap0 = (NTAPS == 27) ? wave * TAPW : 0;
+
+    f32x4_t acc[TAPW][CT][CT];
+#pragma unroll
+    for (int t = 0; t < TAPW; ++t)
+#pragma unroll
+        for (int a = 0; a < CT; ++a)
+#pragma unroll
+            for (int b = 0; b < CT; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+        const int th_i = t % p.tiles_h; t /= p.tiles_h;
+        const int td_i = t % p.tiles_d; t /= p.tiles_d;
+        const int n = t;
+        const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+        __syncthreads();
+        // ---- stage P: TV rows x CBW channels ----
+        for (int i = tid; i < TV * 4; i += 256) {
+            const int cq = i & 3, tv = i >> 2;
+            const int c = mblk * CBW + cq * EPC;
+            const int td = tv / (TH * TW), th = (tv / TW) % TH, tw = tv % TW;
+            const int d = d0 + td, h = h0 + th, w = w0 + tw;
+            u32x4_t val = {0u, 0u, 0u, 0u};
+            if (d < p.D && h < p.H && w < p.W && c < p.M) {
+                const long long vox = (((long long)n * p.D + d) * p.H + h) * p.W + w;
+                const T* src = pg + vox * p.ldp + c;
+                if (c + EPC <= p.M) {
+                    val = *(const u32x4_t*)src;
+                } else {
+                    alignas(16) T tmp[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) DT<T>::st(&tmp[e], (c + e < p.M) ? DT<T>::ld(src + e) : 0.f);
+                    val = *(const u32x4_t*)tmp;
+                }
+            }
+            *(u32x4_t*)(ldsP + tv * RS + cq * 16) = val;
+        }
+        // ---- stage Q: HV rows x CBW channels ----
+        for (int i = tid; i < HV * 4; i += 256) {
+            const int cq = i & 3, hv = i >> 2;
+            const int c = kblk * CBW + cq * EPC;
+            u32x4_t val = {0u, 0u, 0u, 0u};
+            if constexpr (QSRC == Q_DIRECT) {
+                const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
+                const int d = d0 - PAD + hd, h = h0 - PAD + hh, w = w0 - PAD + hw;
+                if (c < p.K && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
+                    const long long vox = (((long long)n * p.D + d) * p.H + h) * p.W + w;
+                    val = *(const u32x4_t*)(qg + vox * p.ldq + c);
+                }
+            } else if constexpr (QSRC == Q_GATHER) {
+                const int ov = w0 + hv;
+                if (ov < p.W && c < p.K) {
+                    int tt = ov;
+                    const int ow = tt % p.OW; tt /= p.OW;
+                    const int oh = tt % p.OH; tt /= p.OH;
+                    const int od = tt % p.OD; const int nn = tt / p.OD;
+                    alignas(16) T tmp[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const int vc = c + e;
+                        float fv = 0.f;
+                        if (vc < p.K) {
+                            const int tap = vc / p.cin, ci = vc - tap * p.cin;
+                            const int kw = tap % p.k, kh = (tap / p.k) % p.k, kd = tap / (p.k * p.k);
+                            const int id = od * p.s - p.p + kd, ih = oh * p.s - p.p + kh, iw = ow * p.s - p.p + kw;
+                            if ((unsigned)id < (unsigned)p.ID && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
+                                const long long vox = (((long long)nn * p.ID + id) * p.IH + ih) * p.IW + iw;
+                                fv = DT<T>::ld(qg + vox * p.ldq + ci);
+                            }
+                        }
+                        DT<T>::st(&tmp[e], fv);
+                    }
+                    val = *(const u32x4_t*)tmp;
+                }
+            } else {  // Q_DECONV: virtual channel (abc, co) of coarse voxel = fine child abc, channel co
+                const int cv = w0 + hv;
+                if (cv < p.W && c < p.K) {
+                    int tt = cv;
+                    const int cw = tt % p.OW; tt /= p.OW;
+                    const int ch = tt % p.OH; tt /= p.OH;
+                    const int cd = tt % p.OD; const int nn = tt / p.OD;
+                    const int abc = c / p.creal, co = c - abc * p.creal;
+                    const int fd = 2 * cd + (abc >> 2), fh = 2 * ch + ((abc >> 1) & 1), fw = 2 * cw + (abc & 1);
+                    const long long vox = (((long long)nn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
+                    val = *(const u32x4_t*)(qg + vox * p.ldq + co);
+                }
+            }
+            *(u32x4_t*)(ldsQ + hv * RS + cq * 16) = val;
+        }
+        __syncthreads();
+        // ---- MFMA over the tile's voxels ----
+        const int ks_begin = (NTAPS == 27) ? 0 : wave;
+        const int ks_step = (NTAPS == 27) ? 1 : C::WAVES;
+        for (int ks = ks_begin; ks < NKS; ks += ks_step) {
+            if constexpr (sizeof(T) == 2) {
+                // lane = 16*g + 4*qr + pc : group g covers voxels ks*32 + 8g + {0..7}; this lane supplies the
+                // address of block row qr (voxel) and the 4 channels 4*pc.. of the 16-channel tile.
+                const int g = lane >> 4, qr = (lane >> 2) & 3, pc = lane & 3;
+                int prow[2], qrow[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int tv = ks * 32 + 8 * g + 4 * i + qr;
+                    const int td = tv / (TH * TW), th = (tv / TW) % TH, tw = tv % TW;
+                    prow[i] = tv * RS + pc * 8;
+                    qrow[i] = ((td * PH + th) * PW + tw) * RS + pc * 8;
+                }
+                u32x4_t pf[CT];
+#pragma unroll
+                for (int a = 0; a < CT; ++a) {
+                    bf16x4_t lo = lds_tr_read(ldsP + prow[0] + a * 32);
+                    bf16x4_t hi = lds_tr_read(ldsP + prow[1] + a * 32);
+                    bf16x8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    pf[a] = __builtin_bit_cast(u32x4_t, f);
+                }
+#pragma unroll
+                for (int tt = 0; tt < TAPW; ++tt) {
+                    const int tap = tap0 + tt;
+                    if (tap >= NTAPS) break;
+                    int toff = 0;
+                    if constexpr (NTAPS == 27) {
+                        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                        toff = ((kd * PH + kh) * PW + kw) * RS;
+                    }
+#pragma unroll
+                    for (int b = 0; b < CT; ++b) {
+                        bf16x4_t lo = lds_tr_read(ldsQ + qrow[0] + toff + b * 32);
+                        bf16x4_t hi = lds_tr_read(ldsQ + qrow[1] + toff + b * 32);
+                        bf16x8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const u32x4_t qf = __builtin_bit_cast(u32x4_t, f);
+#pragma unroll
+                        for (int a = 0; a < CT; ++a) mma_chunk<bf16_t>(acc[tt][a][b], pf[a], qf);
+                    }
+                }
+            } else {
+                const int r = lane & 15, q = lane >> 4;
+                const int tv = ks * 4 + q;
+                const int td = tv / (TH * TW), th = (tv / TW) % TH, tw = tv % TW;
+                const float pv = *(const float*)(ldsP + tv * RS + r * 4);
+                const int qrow = ((td * PH + th) * PW + tw) * RS + r * 4;
+#pragma unroll
+                for (int tt = 0; tt < TAPW; ++tt) {
+                    const int tap = tap0 + tt;
+                    if (tap >= NTAPS) break;
+                    int toff = 0;
+                    if constexpr (NTAPS == 27) {
+                        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                        toff = ((kd * PH + kh) * PW + kw) * RS;
+                    }
+                    const float qv = *(const float*)(ldsQ + qrow + toff);
+                    acc[tt][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, qv, acc[tt][0][0], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- write this workgroup's (wave's) partial slab ----
+    const int nslot_wave = (NTAPS == 27) ? 1 : C::WAVES;
+    const long long slot = (long long)blockIdx.x * nslot_wave + ((NTAPS == 27) ? 0 : wave);
+    const long long nslots = (long long)gridDim.x * nslot_wave;
+    float* slab = p.slabs + ((long long)blockIdx.y * nslots + slot) * C::SLAB_FLOATS;
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int tt = 0; tt < TAPW; ++tt) {
+        const int tap = tap0 + tt;
+        if (tap >= NTAPS) break;
+#pragma unroll
+        for (int a = 0; a < CT; ++a)
+#pragma unroll
+            for (int b = 0; b < CT; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    slab[(tap * CBW + a * 16 + q * 4 + e) * CBW + b * 16 + r] = acc[tt][a][b][e];
+    }
+}
+
+struct ReduceParams {
+    const float* slabs;
+    float* dw;
+    int M, M0, T, K, K0;
+    long long s_m1, s_m0, s_t, s_k1, s_k0;
+    int mblks, kblks, nslots, cbw, accumulate;
+};
+
+__global__ void wgrad_reduce_kernel(const ReduceParams p) {
+    const long long total = (long long)p.M * p.T * p.K;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % p.K);
+        const int t = (int)((i / p.K) % p.T);
+        const int m = (int)(i / ((long long)p.K * p.T));
+        const int mb = m / p.cbw, ml = m % p.cbw, kb = k / p.cbw, kl = k % p.cbw;
+        const long long slabf = (long long)p.T * p.cbw * p.cbw;
+        const float* src = p.slabs + ((long long)(mb * p.kblks + kb) * p.nslots) * slabf +
+                           ((long long)t * p.cbw + ml) * p.cbw + kl;
+        float s = 0.f;
+        for (int sl = 0; sl < p.nslots; ++sl) s += src[(long long)sl * slabf];
+        const long long di = (long long)(m / p.M0) * p.s_m1 + (long long)(m % p.M0) * p.s_m0 + (long long)t * p.s_t +
+                             (long long)(k / p.K0) * p.s_k1 + (long long)(k % p.K0) * p.s_k0;
+        p.dw[di] = p.accumulate ? p.dw[di] + s : s;
+    }
+}
+
+template <typename T, int NTAPS, int QSRC, int TD, int TH, int TW>
+int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes, hipStream_t stream) {
+    using C = WgCfg<T, NTAPS, TD, TH, TW>;
+    p.tiles_d = ceil_div(p.D, TD);
+    p.tiles_h = ceil_div(p.H, TH);
+    p.tiles_w = ceil_div(p.W, TW);
+    const long long nt = (long long)p.N * p.tiles_d * p.tiles_h * p.tiles_w;
+    if (nt > 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "wgrad: too many tiles");
+    p.ntiles = (int)nt;
+    p.mblks = ceil_div(p.M, C::CBW);
+    p.kblks = ceil_div(p.K, C::CBW);
+    const int pairs = p.mblks * p.kblks;
+    const int wave_slots = (NTAPS == 27) ? 1 : C::WAVES;
+    const size_t slab_bytes = (size_t)C::SLAB_FLOATS * 4;
+    long long gx = msseg_num_cus() * ((C::LDS_BYTES > 80 * 1024) ? 1 : 2);
+    if (pairs > 1) gx = (gx + pairs - 1) / pairs;
+    if (gx > p.ntiles) gx = p.ntiles;
+    const long long fit = (long long)(ws_bytes / (slab_bytes * pairs * wave_slots));
+    if (fit < 1) MSSEG_FAIL(MSSEG_EWORKSPACE, "wgrad: workspace %zu B too small (need >= %zu)", ws_bytes,
+                            slab_bytes * pairs * wave_slots);
+    if (gx > fit) gx = fit;
+    if (gx < 1) gx = 1;
+    p.slabs = (float*)workspace;
+    auto kern = igemm_wgrad_kernel<T, NTAPS, QSRC, TD, TH, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+            MSSEG_FAIL(MSSEG_ELAUNCH, "wgrad: cannot set dynamic LDS size %d", C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, pairs, 1), dim3(256), C::LDS_BYTES, stream, p);
+    MSSEG_CHECK_LAUNCH("igemm_wgrad");
+    rp.slabs = p.slabs;
+    rp.mblks = p.mblks; rp.kblks = p.kblks; rp.nslots = (int)gx * wave_slots; rp.cbw = C::CBW;
+    const long long total = (long long)rp.M * rp.T * rp.K;
+    int rb = (int)((total + 255) / 256);
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, rp);
+    MSSEG_CHECK_LAUNCH("wgrad_reduce");
+    return MSSEG_OK;
+}
+
+template <typename T> int launch_wg_k3(WgradParams& p, ReduceParams& rp, void* ws, size_t wsb, hipStream_t st) {
+    const int mn = p.D < p.H ? (p.D < p.W ? p.D : p.W) : (p.H < p.W ? p.H : p.W);
+    if (mn >= 32) return launch_wg<T, 27, Q_DIRECT, 4, 8, 16>(p, rp, ws, wsb, st);
+    if (mn >= 12) return launch_wg<T, 27, Q_DIRECT, 4, 4, 8>(p, rp, ws, wsb, st);
+    return launch_wg<T, 27, Q_DIRECT, 2, 4, 8>(p, rp, ws, wsb, st);
+}
+
+int wg_check(const void* a, long long lda, const void* b, long long ldb, const void* dw, const void* ws, int dtype) {
+    if (!a || !b || !dw || !ws) MSSEG_FAIL(MSSEG_EINVAL, "wgrad: null pointer");
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "wgrad: bad dtype");
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)ws) & 15) || (lda * esz) % 16 || (ldb * esz) % 16)
+        MSSEG_FAIL(MSSEG_EINVAL, "wgrad: operands must be 16-byte aligned with 16-byte row strides");
+    return MSSEG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t msseg_wgrad_workspace_bytes(int M, int T, int K) {
+    // worst case over dtypes: f32 blocks are 16 wide, bf16 32 wide; sized for a full-chip persistent grid
+    const size_t padM = (size_t)((M + 31) / 32) * 32, padK = (size_t)((K + 31) / 32) * 32;
+    const size_t per_slot = padM * padK * (size_t)T * 4;
+    size_t slots = 256;
+    // large-channel layers live on small grids: bound the scratch at ~256 MiB
+    while (slots > 8 && per_slot * slots * (T == 1 ? 4 : 1) > ((size_t)256 << 20)) slots /= 2;
+    return per_slot * slots * (T == 1 ? 4 : 1);
+}
+
+int msseg_conv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, int N, int D, int H,
+                          int W, int Cin, int Cout, int accumulate, void* workspace, size_t workspace_bytes, int dtype,
+                          msseg_stream_t stream) {
+    int rc = wg_check(x, ldx, dy, lddy, dw, workspace, dtype);
+    if (rc) return rc;
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    if (Cin % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_wgrad: Cin %% %d != 0", 16 / esz);
+    WgradParams p{};
+    p.pten = dy; p.ldp = lddy; p.qten = x; p.ldq = ldx;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.M = Cout; p.K = Cin;
+    ReduceParams rp{};
+    rp.dw = dw; rp.M = Cout; rp.M0 = Cout; rp.T = 27; rp.K = Cin; rp.K0 = Cin;
+    rp.s_m1 = 0; rp.s_m0 = (long long)Cin * 27; rp.s_t = 1; rp.s_k1 = 0; rp.s_k0 = 27; rp.accumulate = accumulate;
+    return dtype == MSSEG_F32 ? launch_wg_k3<float>(p, rp, workspace, workspace_bytes, (hipStream_t)stream)
+                              : launch_wg_k3<bf16_t>(p, rp, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int msseg_conv3d_k1_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, long long NV, int Cin,
+                          int Cout, int accumulate, void* workspace, size_t workspace_bytes, int dtype,
+                          msseg_stream_t stream) {
+    int rc = wg_check(x, ldx, dy, lddy, dw, workspace, dtype);
+    if (rc) return rc;
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    if (Cin % (16 / esz) || NV < 1 || NV > 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_wgrad: bad shape");
+    WgradParams p{};
+    p.pten = dy; p.ldp = lddy; p.qten = x; p.ldq = ldx;
+    p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.M = Cout; p.K = Cin;
+    ReduceParams rp{};
+    rp.dw = dw; rp.M = Cout; rp.M0 = Cout; rp.T = 1; rp.K = Cin; rp.K0 = Cin;
+    rp.s_m0 = Cin; rp.s_k0 = 1; rp.accumulate = accumulate;
+    return dtype == MSSEG_F32
+               ? launch_wg<float, 1, Q_DIRECT, 1, 1, 256>(p, rp, workspace, workspace_bytes, (hipStream_t)stream)
+               : launch_wg<bf16_t, 1, Q_DIRECT, 1, 1, 256>(p, rp, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int msseg_conv3d_gather_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, int N, int ID,
+                              int IH, int IW, int Cin, int Cout, int k, int s, int pd, int accumulate, void* workspace,
+                              size_t workspace_bytes, int dtype, msseg_stream_t stream) {
+    if (!x || !dy || !dw || !workspace) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: null pointer");
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: bad dtype");
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    if (((uintptr_t)dy & 15) || (lddy * esz) % 16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: dy alignment");
+    if (k < 1 || s < 1 || pd < 0 || Cin * k * k * k > 128) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: bad kernel");
+    const int OD = (ID + 2 * pd - k) / s + 1, OH = (IH + 2 * pd - k) / s + 1, OW = (IW + 2 * pd - k) / s + 1;
+    const long long NV = (long long)N * OD * OH * OW;
+    if (OD < 1 || OH < 1 || OW < 1 || NV > 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: bad shape");
+    const int KT = k * k * k;
+    WgradParams p{};
+    p.pten = dy; p.ldp = lddy; p.qten = x; p.ldq = ldx;
+    p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.M = Cout; p.K = Cin * KT;
+    p.ID = ID; p.IH = IH; p.IW = IW; p.OD = OD; p.OH = OH; p.OW = OW; p.cin = Cin; p.k = k; p.s = s; p.p = pd;
+    ReduceParams rp{};
+    // logical k = tap*Cin + ci  ->  torch [Cout][Cin][KT]
+    rp.dw = dw; rp.M = Cout; rp.M0 = Cout; rp.T = 1; rp.K = Cin * KT; rp.K0 = Cin;
+    rp.s_m0 = (long long)Cin * KT; rp.s_k1 = 1; rp.s_k0 = KT; rp.accumulate = accumulate;
+    return dtype == MSSEG_F32
+               ? launch_wg<float, 1, Q_GATHER, 1, 1, 256>(p, rp, workspace, workspace_bytes, (hipStream_t)stream)
+               : launch_wg<bf16_t, 1, Q_GATHER, 1, 1, 256>(p, rp, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int msseg_deconv_k2s2_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, int N, int D, int H,
+                            int W, int Cin, int Cout, int accumulate, void* workspace, size_t workspace_bytes,
+                            int dtype, msseg_stream_t stream) {
+    int rc = wg_check(x, ldx, dy, lddy, dw, workspace, dtype);
+    if (rc) return rc;
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    const long long NV = (long long)N * D * H * W;
+    if (Cout % (16 / esz) || NV < 1 || NV > 0x7fffffffLL / 8) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_wgrad: bad shape");
+    WgradParams p{};
+    p.pten = x; p.ldp = ldx; p.qten = dy; p.ldq = lddy;
+    p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.M = Cin; p.K = 8 * Cout;
+    p.OD = D; p.OH = H; p.OW = W; p.creal = Cout;
+    ReduceParams rp{};
+    // logical [m = ci][k = abc*Cout + co] -> torch ConvTranspose3d weight [Cin][Cout][2][2][2]
+    rp.dw = dw; rp.M = Cin; rp.M0 = Cin; rp.T = 1; rp.K = 8 * Cout; rp.K0 = Cout;
+    rp.s_m0 = (long long)Cout * 8; rp.s_k1 = 1; rp.s_k0 = 8; rp.accumulate = accumulate;
+    return dtype == MSSEG_F32
+               ? launch_wg<float, 1, Q_DECONV, 1, 1, 256>(p, rp, workspace, workspace_bytes, (hipStream_t)stream)
+               : launch_wg<bf16_t, 1, Q_DECONV, 1, 1, 256>(p, rp, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

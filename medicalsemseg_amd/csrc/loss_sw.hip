@@ -1,0 +1,337 @@
+// Dice + cross-entropy loss (single pass over logits/labels forward, single pass backward), hard Dice
+// metric counts, and the sliding-window gather / blend / normalise kernels.
+#include "common.h"
+
+namespace {
+
+enum { LAB_F32 = 0, LAB_BF16 = 1, LAB_U8 = 2, LAB_I64 = 3 };
+
+MSSEG_DEVFN int load_label(const void* labels, int label_dtype, long long idx) {
+    switch (label_dtype) {
+        case LAB_F32: return (int)((const float*)labels)[idx];
+        case LAB_BF16: return (int)(float)((const bf16_t*)labels)[idx];
+        case LAB_U8: return (int)((const uint8_t*)labels)[idx];
+        default: return (int)((const long long*)labels)[idx];
+    }
+}
+
+template <typename T, int CMAX>
+MSSEG_DEVFN void load_logits(const T* base, long long ld, long long S, int C, long long n, long long s, float* x) {
+    // ld > 0: channels-last [N][S][ld]; ld == 0: NCDHW [N][C][S]
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        if (c < C) x[c] = ld > 0 ? DT<T>::ld(base + (n * S + s) * ld + c) : DT<T>::ld(base + (n * C + c) * S + s);
+        else x[c] = -INFINITY;
+    }
+}
+
+template <int CMAX> MSSEG_DEVFN void softmax_inplace(float* x, int C, float& lse) {
+    float mx = x[0];
+#pragma unroll
+    for (int c = 1; c < CMAX; ++c) mx = fmaxf(mx, x[c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        x[c] = (c < C) ? expf(x[c] - mx) : 0.f;
+        sum += x[c];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) x[c] *= inv;
+    lse = mx + logf(sum);
+}
+
+// partial[n][c][0..3] += (sum p*t, sum p^2, sum t, -sum t*log p); hard[n][c][0..2] += (|P&T|, |P|, |T|)
+template <typename T, int CMAX>
+__global__ __launch_bounds__(256) void dice_ce_partials_kernel(const T* __restrict__ logits, long long ld,
+                                                               const void* __restrict__ labels, int label_dtype,
+                                                               float* partial, float* hard, long long S, int C,
+                                                               long long vox_per_block) {
+    __shared__ float red[4][CMAX * 7];
+    const long long n = blockIdx.y;
+    const long long s0 = (long long)blockIdx.x * vox_per_block;
+    long long s1 = s0 + vox_per_block;
+    if (s1 > S) s1 = S;
+    float acc[CMAX][7];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[c][k] = 0.f;
+    for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
+        float x[CMAX];
+        load_logits<T, CMAX>(logits, ld, S, C, n, s, x);
+        int am = 0;
+        float best = x[0];
+#pragma unroll
+        for (int c = 1; c < CMAX; ++c)
+            if (c < C && x[c] > best) { best = x[c]; am = c; }
+        float raw[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) raw[c] = x[c];
+        float lse;
+        softmax_inplace<CMAX>(x, C, lse);
+        const int lab = load_label(labels, label_dtype, n * S + s);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < C) {
+                const float t = (lab == c) ? 1.f : 0.f;
+                acc[c][0] += x[c] * t;
+                acc[c][1] += x[c] * x[c];
+                acc[c][2] += t;
+                acc[c][3] += t * (lse - raw[c]);
+                const float pm = (am == c) ? 1.f : 0.f;
+                acc[c][4] += pm * t;
+                acc[c][5] += pm;
+                acc[c][6] += t;
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float v = wave_sum(acc[c][k]);
+            if (lane == 0) red[wave][c * 7 + k] = v;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 7; i += 256) {
+        const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        const int c = i / 7, k = i % 7;
+        if (k < 4) {
+            if (partial) atomicAdd(&partial[(n * C + c) * 4 + k], v);
+        } else if (hard) {
+            atomicAdd(&hard[(n * C + c) * 3 + (k - 4)], v);
+        }
+    }
+}
+
+__global__ void dice_ce_finalize_kernel(const float* partial, float* loss, int N, long long S, int C, float snr,
+                                        float sdr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float dice = 0.f, ce = 0.f;
+    for (int i = 0; i < N * C; ++i) {
+        const float I = partial[i * 4 + 0], p2 = partial[i * 4 + 1], t = partial[i * 4 + 2];
+        dice += 1.f - (2.f * I + snr) / (p2 + t + sdr);
+        ce += partial[i * 4 + 3];
+    }
+    dice /= (float)(N * C);
+    ce /= (float)((double)N * (double)S);
+    loss[0] = dice + ce;
+    loss[1] = dice;
+    loss[2] = ce;
+}
+
+template <typename T, int CMAX>
+__global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const T* __restrict__ logits, long long ld,
+                                                          const void* __restrict__ labels, int label_dtype,
+                                                          const float* __restrict__ partial, const float* gscale,
+                                                          T* __restrict__ dlogits, long long ldd, int N, long long S,
+                                                          int C, float snr, float sdr) {
+    const long long n = blockIdx.y;
+    // per (n, c) constants of d dice / d p
+    float ka[CMAX], kb[CMAX];
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float wd = gs / (float)(N * C);
+    const float wc = gs / (float)((double)N * (double)S);
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        ka[c] = kb[c] = 0.f;
+        if (c < C) {
+            const float I = partial[(n * C + c) * 4 + 0], p2 = partial[(n * C + c) * 4 + 1], t = partial[(n * C + c) * 4 + 2];
+            const float den = p2 + t + sdr, num = 2.f * I + snr;
+            ka[c] = -2.f / den * wd;              // multiplies t
+            kb[c] = 2.f * num / (den * den) * wd;  // multiplies p
+        }
+    }
+    for (long long s = blockIdx.x * 256LL + threadIdx.x; s < S; s += (long long)gridDim.x * 256) {
+        float x[CMAX];
+        load_logits<T, CMAX>(logits, ld, S, C, n, s, x);
+        float lse;
+        softmax_inplace<CMAX>(x, C, lse);
+        const int lab = load_label(labels, label_dtype, n * S + s);
+        float g[CMAX], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            const float t = (lab == c) ? 1.f : 0.f;
+            g[c] = (c < C) ? (ka[c] * t + kb[c] * x[c]) : 0.f;
+            dot += g[c] * x[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < C) {
+                const float t = (lab == c) ? 1.f : 0.f;
+                const float d = x[c] * (g[c] - dot) + wc * (x[c] - t);
+                if (ldd > 0) DT<T>::st(dlogits + (n * S + s) * ldd + c, d);
+                else DT<T>::st(dlogits + (n * C + c) * S + s, d);
+            }
+        }
+        if (ldd > C) {
+            for (int c = C; c < ldd; ++c) DT<T>::st(dlogits + (n * S + s) * ldd + c, 0.f);
+        }
+    }
+}
+
+// ---------------- sliding window ----------------
+template <typename T>
+__global__ void sw_blend_kernel(const T* __restrict__ win, long long ld, const float* __restrict__ imp,
+                                float* __restrict__ out, float* __restrict__ cnt, int C, int VD, int VH, int VW,
+                                int RD, int RH, int RW, int z0, int y0, int x0) {
+    const long long R = (long long)RD * RH * RW, V = (long long)VD * VH * VW;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < R; i += (long long)gridDim.x * 256) {
+        const int rx = (int)(i % RW), ry = (int)((i / RW) % RH), rz = (int)(i / ((long long)RW * RH));
+        const long long v = ((long long)(z0 + rz) * VH + (y0 + ry)) * VW + (x0 + rx);
+        const float w = imp[i];
+        for (int c = 0; c < C; ++c) {
+            const float val = ld > 0 ? DT<T>::ld(win + i * ld + c) : DT<T>::ld(win + c * R + i);
+            out[c * V + v] += w * val;
+        }
+        cnt[v] += w;
+    }
+}
+
+__global__ void sw_normalize_kernel(float* out, const float* cnt, int C, long long V) {
+    const long long total = (long long)C * V;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        out[i] = out[i] / cnt[i % V];
+}
+
+template <typename T>
+__global__ void sw_gather_kernel(const float* __restrict__ vol, T* __restrict__ win, int C, int VD, int VH, int VW,
+                                 int RD, int RH, int RW, int z0, int y0, int x0, float cval) {
+    const long long R = (long long)RD * RH * RW, V = (long long)VD * VH * VW;
+    const long long total = R * C;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long ri = i % R;
+        const int c = (int)(i / R);
+        const int rx = (int)(ri % RW), ry = (int)((ri / RW) % RH), rz = (int)(ri / ((long long)RW * RH));
+        const int z = z0 + rz, y = y0 + ry, x = x0 + rx;
+        float v = cval;
+        if ((unsigned)z < (unsigned)VD && (unsigned)y < (unsigned)VH && (unsigned)x < (unsigned)VW)
+            v = vol[c * V + ((long long)z * VH + y) * VW + x];
+        DT<T>::st(win + i, v);
+    }
+}
+
+inline int grid_for(long long total, int per_thread = 4) {
+    long long b = ceil_div_ll(total, 256LL * per_thread);
+    const long long cap = (long long)msseg_num_cus() * 16;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <typename T, int CMAX>
+int launch_partials(const void* logits, long long ld, const void* labels, int label_dtype, float* partial, float* hard,
+                    int N, long long S, int C, hipStream_t st) {
+    long long blocks = ceil_div_ll(S, 256LL * 8);
+    const long long cap = (long long)msseg_num_cus() * 8 / N + 1;
+    if (blocks > cap) blocks = cap;
+    const long long vpb = ceil_div_ll(S, blocks);
+    blocks = ceil_div_ll(S, vpb);
+    hipLaunchKernelGGL((dice_ce_partials_kernel<T, CMAX>), dim3((unsigned)blocks, N), dim3(256), 0, st, (const T*)logits,
+                       ld, labels, label_dtype, partial, hard, S, C, vpb);
+    MSSEG_CHECK_LAUNCH("dice_ce_partials");
+    return MSSEG_OK;
+}
+
+template <typename T, int CMAX>
+int launch_bwd(const void* logits, long long ld, const void* labels, int label_dtype, const float* partial,
+               const float* gscale, void* dlogits, long long ldd, int N, long long S, int C, float snr, float sdr,
+               hipStream_t st) {
+    long long blocks = ceil_div_ll(S, 256LL * 4);
+    const long long cap = (long long)msseg_num_cus() * 16 / N + 1;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((dice_ce_bwd_kernel<T, CMAX>), dim3((unsigned)blocks, N), dim3(256), 0, st, (const T*)logits, ld,
+                       labels, label_dtype, partial, gscale, (T*)dlogits, ldd, N, S, C, snr, sdr);
+    MSSEG_CHECK_LAUNCH("dice_ce_bwd");
+    return MSSEG_OK;
+}
+
+}  // namespace
+
+#define DISPATCH_TC(dtype, C, FN, ...)                                                        \
+    do {                                                                                      \
+        if ((dtype) == MSSEG_F32) {                                                           \
+            if ((C) <= 4) return FN<float, 4>(__VA_ARGS__);                                   \
+            if ((C) <= 8) return FN<float, 8>(__VA_ARGS__);                                   \
+            return FN<float, 16>(__VA_ARGS__);                                                \
+        } else if ((dtype) == MSSEG_BF16) {                                                   \
+            if ((C) <= 4) return FN<bf16_t, 4>(__VA_ARGS__);                                  \
+            if ((C) <= 8) return FN<bf16_t, 8>(__VA_ARGS__);                                  \
+            return FN<bf16_t, 16>(__VA_ARGS__);                                               \
+        }                                                                                     \
+        MSSEG_FAIL(MSSEG_EINVAL, "bad dtype %d", (int)(dtype));                               \
+    } while (0)
+
+extern "C" {
+
+int msseg_dice_ce_partials(const void* logits, long long ld, int dtype, const void* labels, int label_dtype,
+                           float* partial, float* hard, int N, long long S, int C, msseg_stream_t stream) {
+    if (!logits || !labels || (!partial && !hard) || N < 1 || S < 1 || C < 1 || C > 16 || (ld != 0 && ld < C) ||
+        label_dtype < 0 || label_dtype > 3)
+        MSSEG_FAIL(MSSEG_EINVAL, "dice_ce_partials: bad args (C=%d must be 1..16)", C);
+    DISPATCH_TC(dtype, C, launch_partials, logits, ld, labels, label_dtype, partial, hard, N, S, C, (hipStream_t)stream);
+}
+
+int msseg_dice_ce_finalize(const float* partial, float* loss, int N, long long S, int C, float smooth_nr,
+                           float smooth_dr, msseg_stream_t stream) {
+    if (!partial || !loss || N < 1 || S < 1 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "dice_ce_finalize: bad args");
+    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, loss, N, S, C,
+                       smooth_nr, smooth_dr);
+    MSSEG_CHECK_LAUNCH("dice_ce_finalize");
+    return MSSEG_OK;
+}
+
+int msseg_dice_ce_bwd(const void* logits, long long ld, int dtype, const void* labels, int label_dtype,
+                      const float* partial, const float* gscale, void* dlogits, long long ldd, int N, long long S, int C,
+                      float smooth_nr, float smooth_dr, msseg_stream_t stream) {
+    if (!logits || !labels || !partial || !dlogits || N < 1 || S < 1 || C < 1 || C > 16 || (ld != 0 && ld < C) ||
+        (ldd != 0 && ldd < C) || label_dtype < 0 || label_dtype > 3)
+        MSSEG_FAIL(MSSEG_EINVAL, "dice_ce_bwd: bad args");
+    DISPATCH_TC(dtype, C, launch_bwd, logits, ld, labels, label_dtype, partial, gscale, dlogits, ldd, N, S, C, smooth_nr,
+                smooth_dr, (hipStream_t)stream);
+}
+
+int msseg_sw_blend(const void* win, long long ld, int dtype, const float* imp, float* out, float* cnt, int C, int VD,
+                   int VH, int VW, int RD, int RH, int RW, int z0, int y0, int x0, msseg_stream_t stream) {
+    if (!win || !imp || !out || !cnt || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "sw_blend: bad args");
+    if (z0 < 0 || y0 < 0 || x0 < 0 || z0 + RD > VD || y0 + RH > VH || x0 + RW > VW)
+        MSSEG_FAIL(MSSEG_EINVAL, "sw_blend: window (%d,%d,%d)+(%d,%d,%d) outside volume (%d,%d,%d)", z0, y0, x0, RD, RH,
+                   RW, VD, VH, VW);
+    const int g = grid_for((long long)RD * RH * RW, 1);
+    if (dtype == MSSEG_F32)
+        hipLaunchKernelGGL(sw_blend_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)win, ld, imp,
+                           out, cnt, C, VD, VH, VW, RD, RH, RW, z0, y0, x0);
+    else if (dtype == MSSEG_BF16)
+        hipLaunchKernelGGL(sw_blend_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)win, ld,
+                           imp, out, cnt, C, VD, VH, VW, RD, RH, RW, z0, y0, x0);
+    else MSSEG_FAIL(MSSEG_EINVAL, "sw_blend: bad dtype");
+    MSSEG_CHECK_LAUNCH("sw_blend");
+    return MSSEG_OK;
+}
+
+int msseg_sw_normalize(float* out, const float* cnt, int C, long long V, msseg_stream_t stream) {
+    if (!out || !cnt || C < 1 || V < 1) MSSEG_FAIL(MSSEG_EINVAL, "sw_normalize: bad args");
+    hipLaunchKernelGGL(sw_normalize_kernel, dim3(grid_for((long long)C * V)), dim3(256), 0, (hipStream_t)stream, out, cnt,
+                       C, V);
+    MSSEG_CHECK_LAUNCH("sw_normalize");
+    return MSSEG_OK;
+}
+
+int msseg_sw_gather(const float* vol, void* win, int dtype, int C, int VD, int VH, int VW, int RD, int RH, int RW, int z0,
+                    int y0, int x0, float cval, msseg_stream_t stream) {
+    if (!vol || !win || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "sw_gather: bad args");
+    const int g = grid_for((long long)C * RD * RH * RW);
+    if (dtype == MSSEG_F32)
+        hipLaunchKernelGGL(sw_gather_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, vol, (float*)win, C, VD, VH,
+                           VW, RD, RH, RW, z0, y0, x0, cval);
+    else if (dtype == MSSEG_BF16)
+        hipLaunchKernelGGL(sw_gather_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, vol, (bf16_t*)win, C, VD,
+                           VH, VW, RD, RH, RW, z0, y0, x0, cval);
+    else MSSEG_FAIL(MSSEG_EINVAL, "sw_gather: bad dtype");
+    MSSEG_CHECK_LAUNCH("sw_gather");
+    return MSSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,449 @@
+"""ctypes binding of ``libmsseg_hip.so`` (C ABI: ``include/msseg.h``) + thin tensor-level wrappers.
+
+There is NO CPU fallback: if the shared library is missing, or a tensor is not on a GPU, these
+functions raise.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsseg_hip.so")
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_LAB = {torch.float32: 0, torch.bfloat16: 1, torch.uint8: 2, torch.int64: 3}
+
+_lib = None
+
+_vp, _ll, _i, _f, _sz = C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_size_t
+
+# name -> argtypes (every symbol include/msseg.h declares; tests check the .so exports all of them)
+SIGNATURES = {
+    "msseg_abi_version": ([], _i),
+    "msseg_last_error": ([], C.c_char_p),
+    "msseg_num_cus": ([], _i),
+    "msseg_packed_weight_bytes": ([_i, _i, _i, _i, _i], _sz),
+    "msseg_pack_weights": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp], _i),
+    "msseg_cout_block": ([_i], _i),
+    "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_conv3d_k1_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
+    "msseg_conv3d_gather_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_deconv_k2s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_deconv_k2s2_bwd_data": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_wgrad_workspace_bytes": ([_i, _i, _i], _sz),
+    "msseg_conv3d_k3_wgrad": ([_vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
+    "msseg_conv3d_k1_wgrad": ([_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _sz, _i, _vp], _i),
+    "msseg_conv3d_gather_wgrad": ([_vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
+    "msseg_deconv_k2s2_wgrad": ([_vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
+    "msseg_channel_stats": ([_vp, _ll, _vp, _i, _ll, _i, _i, _vp], _i),
+    "msseg_instnorm_act_fwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
+    "msseg_instnorm_act_bwd_reduce": ([_vp, _ll, _vp, _vp, _ll, _vp, _ll, _vp, _i, _ll, _i, _f, _f, _i, _vp], _i),
+    "msseg_instnorm_act_bwd_apply": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
+    "msseg_maxpool2_fwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_maxpool2_bwd": ([_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_ncdhw_to_ndhwc": ([_vp, _i, _vp, _ll, _i, _i, _i, _ll, _vp], _i),
+    "msseg_ndhwc_to_ncdhw": ([_vp, _ll, _i, _vp, _i, _i, _i, _ll, _vp], _i),
+    "msseg_channel_sum": ([_vp, _ll, _vp, _ll, _i, _i, _i, _vp], _i),
+    "msseg_add": ([_vp, _ll, _vp, _ll, _vp, _ll, _ll, _i, _i, _vp], _i),
+    "msseg_dice_ce_partials": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _i, _ll, _i, _vp], _i),
+    "msseg_dice_ce_finalize": ([_vp, _vp, _i, _ll, _i, _f, _f, _vp], _i),
+    "msseg_dice_ce_bwd": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, _ll, _i, _f, _f, _vp], _i),
+    "msseg_adamw_step": ([_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _vp], _i),
+    "msseg_sumsq": ([_vp, _ll, _vp, _vp], _i),
+    "msseg_sw_blend": ([_vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_sw_normalize": ([_vp, _vp, _i, _ll, _vp], _i),
+    "msseg_sw_gather": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
+}
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the HIP library and set argtypes.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C medicalsemseg_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, (args, res) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    if lib.msseg_abi_version() != 1:
+        raise RuntimeError("libmsseg_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def lib():
+    return _lib if _lib is not None else load_library()
+
+
+class MssegError(RuntimeError):
+    pass
+
+
+def _ck(rc: int, what: str):
+    if rc != 0:
+        raise MssegError(f"{what} failed ({rc}): {lib().msseg_last_error().decode()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("medicalsemseg_amd kernels run on the GPU only (got a CPU tensor); "
+                               "there is no CPU fallback")
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def ld(t: torch.Tensor) -> int:
+    """voxel stride of a channels-last [..., C] tensor (possibly a channel slice of a wider buffer)."""
+    if t.stride(-1) != 1:
+        raise ValueError("channels-last tensor must have unit channel stride")
+    if t.dim() == 1:
+        return t.shape[0]
+    l = t.stride(-2) if t.shape[-2] > 1 else max(t.shape[-1], t.stride(-2))
+    # leading dims must be dense w.r.t. the voxel stride
+    exp = l
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] > 1 and t.stride(d) != exp:
+            raise ValueError(f"tensor is not a dense channels-last volume: shape {tuple(t.shape)} stride {t.stride()}")
+        exp *= t.shape[d]
+    return l
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------------------------
+def cout_block(M: int) -> int:
+    return lib().msseg_cout_block(M)
+
+
+def pack_weights(src: torch.Tensor, dtype: torch.dtype, M, M0, T, K, K0, s_m1, s_m0, s_t, s_k1, s_k0, flip=False,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_gpu(src)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    cb = cout_block(M)
+    nbytes = lib().msseg_packed_weight_bytes(M, T, K, cb, _DT[dtype])
+    esz = 4 if dtype == torch.float32 else 2
+    if out is None:
+        out = torch.empty(nbytes // esz, dtype=dtype, device=src.device)
+    assert out.numel() * esz == nbytes
+    _ck(lib().msseg_pack_weights(_p(src), _p(out), _DT[dtype], M, M0, T, K, K0, s_m1, s_m0, s_t, s_k1, s_k0,
+                                 int(flip), cb, _stream()), "pack_weights")
+    return out
+
+
+def pack_conv_k3(w: torch.Tensor, dtype, dgrad=False, out=None):
+    """w: [Cout, Cin, 3,3,3] fp32.  Forward image W[co][tap][ci]; dgrad image W'[ci][26-tap][co]."""
+    co, ci = w.shape[0], w.shape[1]
+    if not dgrad:
+        return pack_weights(w, dtype, co, co, 27, ci, ci, 0, ci * 27, 1, 0, 27, False, out)
+    return pack_weights(w, dtype, ci, ci, 27, co, co, 0, 27, 1, 0, ci * 27, True, out)
+
+
+def pack_conv_k1(w: torch.Tensor, dtype, dgrad=False, out=None):
+    co, ci = w.shape[0], w.shape[1]
+    if not dgrad:
+        return pack_weights(w, dtype, co, co, 1, ci, ci, 0, ci, 0, 0, 1, False, out)
+    return pack_weights(w, dtype, ci, ci, 1, co, co, 0, 1, 0, 0, ci, False, out)
+
+
+def pack_conv_gather(w: torch.Tensor, dtype, out=None):
+    """w: [Cout, Cin, k,k,k]; logical K index = tap*Cin + ci."""
+    co, ci = w.shape[0], w.shape[1]
+    kt = w.shape[2] * w.shape[3] * w.shape[4]
+    return pack_weights(w, dtype, co, co, 1, ci * kt, ci, 0, ci * kt, 0, 1, kt, False, out)
+
+
+def pack_deconv(w: torch.Tensor, dtype, bwd=False, out=None):
+    """w: ConvTranspose3d weight [Cin, Cout, 2,2,2].  fwd: M = abc*Cout+co, K = ci.  bwd-data: M = ci, K = abc*Cout+co."""
+    ci, co = w.shape[0], w.shape[1]
+    if not bwd:
+        return pack_weights(w, dtype, 8 * co, co, 1, ci, ci, 1, 8, 0, 0, co * 8, False, out)
+    return pack_weights(w, dtype, ci, ci, 1, 8 * co, co, 0, co * 8, 0, 1, 8, False, out)
+
+
+# --------------------------------------------------------------------------------------------
+# igemm forward-shaped ops.  x, y: [N, D, H, W, C] channels-last (views allowed)
+# --------------------------------------------------------------------------------------------
+def conv3d_k3(x, wp, bias, y, cin, cout):
+    _need_gpu(x, wp, y)
+    N, D, H, W = x.shape[:4]
+    _ck(lib().msseg_conv3d_k3_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, dt(x),
+                                  _stream()), "conv3d_k3_fwd")
+    return y
+
+
+def conv3d_k1(x, wp, bias, y, cin, cout):
+    _need_gpu(x, wp, y)
+    nv = x.numel() // x.shape[-1]
+    _ck(lib().msseg_conv3d_k1_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), nv, cin, cout, dt(x), _stream()),
+        "conv3d_k1_fwd")
+    return y
+
+
+def conv3d_gather(x, wp, bias, y, cin, cout, k, s, p):
+    _need_gpu(x, wp, y)
+    N, D, H, W = x.shape[:4]
+    _ck(lib().msseg_conv3d_gather_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, k, s, p,
+                                      dt(x), _stream()), "conv3d_gather_fwd")
+    return y
+
+
+def deconv_k2s2(x, wp, bias, y, cin, cout):
+    _need_gpu(x, wp, y)
+    N, D, H, W = x.shape[:4]
+    _ck(lib().msseg_deconv_k2s2_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, dt(x),
+                                    _stream()), "deconv_k2s2_fwd")
+    return y
+
+
+def deconv_k2s2_bwd_data(dy, wp, dx, cin, cout):
+    _need_gpu(dy, wp, dx)
+    N, D, H, W = dx.shape[:4]
+    _ck(lib().msseg_deconv_k2s2_bwd_data(_p(dy), ld(dy), _p(wp), _p(dx), ld(dx), N, D, H, W, cin, cout, dt(dy),
+                                         _stream()), "deconv_k2s2_bwd_data")
+    return dx
+
+
+# --------------------------------------------------------------------------------------------
+# weight gradients
+# --------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (stable address => hipGraph friendly)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _wg_ws(M, T, K, device):
+    return workspace(lib().msseg_wgrad_workspace_bytes(M, T, K), device)
+
+
+def conv3d_k3_wgrad(x, dy, dw, cin, cout, accumulate=False):
+    _need_gpu(x, dy, dw)
+    N, D, H, W = x.shape[:4]
+    ws = _wg_ws(cout, 27, cin, x.device)
+    _ck(lib().msseg_conv3d_k3_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), N, D, H, W, cin, cout, int(accumulate),
+                                    _p(ws), ws.numel(), dt(x), _stream()), "conv3d_k3_wgrad")
+
+
+def conv3d_k1_wgrad(x, dy, dw, cin, cout, accumulate=False):
+    _need_gpu(x, dy, dw)
+    nv = x.numel() // x.shape[-1]
+    ws = _wg_ws(cout, 1, cin, x.device)
+    _ck(lib().msseg_conv3d_k1_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), nv, cin, cout, int(accumulate), _p(ws),
+                                    ws.numel(), dt(x), _stream()), "conv3d_k1_wgrad")
+
+
+def conv3d_gather_wgrad(x, dy, dw, cin, cout, k, s, p, accumulate=False):
+    _need_gpu(x, dy, dw)
+    N, D, H, W = x.shape[:4]
+    ws = _wg_ws(cout, 1, cin * k ** 3, x.device)
+    _ck(lib().msseg_conv3d_gather_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), N, D, H, W, cin, cout, k, s, p,
+                                        int(accumulate), _p(ws), ws.numel(), dt(x), _stream()), "conv3d_gather_wgrad")
+
+
+def deconv_k2s2_wgrad(x, dy, dw, cin, cout, accumulate=False):
+    _need_gpu(x, dy, dw)
+    N, D, H, W = x.shape[:4]
+    ws = _wg_ws(cin, 1, 8 * cout, x.device)
+    _ck(lib().msseg_deconv_k2s2_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), N, D, H, W, cin, cout, int(accumulate),
+                                      _p(ws), ws.numel(), dt(x), _stream()), "deconv_k2s2_wgrad")
+
+
+# --------------------------------------------------------------------------------------------
+# norm / act / pool / layout
+# --------------------------------------------------------------------------------------------
+def _nsc(x):
+    N, C = x.shape[0], x.shape[-1]
+    return N, x.numel() // (N * C), C
+
+
+def channel_stats(x, stats=None):
+    _need_gpu(x)
+    N, S, Cc = _nsc(x)
+    if stats is None:
+        stats = torch.zeros(N, Cc, 2, dtype=torch.float32, device=x.device)
+    _ck(lib().msseg_channel_stats(_p(x), ld(x), _p(stats), N, S, Cc, dt(x), _stream()), "channel_stats")
+    return stats
+
+
+def instnorm_act_fwd(x, stats, gamma, beta, y, slope, eps=1e-5, residual=None):
+    _need_gpu(x, stats, y)
+    N, S, Cc = _nsc(x)
+    _ck(lib().msseg_instnorm_act_fwd(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(residual),
+                                     ld(residual) if residual is not None else 0, _p(y), ld(y), N, S, Cc, eps, slope,
+                                     dt(x), _stream()), "instnorm_act_fwd")
+    return y
+
+
+def instnorm_act_bwd(x, stats, gamma, y, dy, dx, slope, eps=1e-5, dres=None):
+    """returns red[N][C][2] = (sum dz, sum dz*xhat): dbeta = red[...,0].sum(0), dgamma = red[...,1].sum(0)."""
+    _need_gpu(x, stats, y, dy, dx)
+    N, S, Cc = _nsc(x)
+    red = torch.zeros(N, Cc, 2, dtype=torch.float32, device=x.device)
+    _ck(lib().msseg_instnorm_act_bwd_reduce(_p(x), ld(x), _p(stats), _p(y), ld(y), _p(dy), ld(dy), _p(red), N, S, Cc,
+                                            eps, slope, dt(x), _stream()), "instnorm_act_bwd_reduce")
+    _ck(lib().msseg_instnorm_act_bwd_apply(_p(x), ld(x), _p(stats), _p(gamma), _p(y), ld(y), _p(dy), ld(dy), _p(red),
+                                           _p(dx), ld(dx), _p(dres), ld(dres) if dres is not None else 0, N, S, Cc, eps,
+                                           slope, dt(x), _stream()), "instnorm_act_bwd_apply")
+    return red
+
+
+def maxpool2_fwd(x, y):
+    _need_gpu(x, y)
+    N, D, H, W, Cc = x.shape
+    _ck(lib().msseg_maxpool2_fwd(_p(x), ld(x), _p(y), ld(y), N, D, H, W, Cc, dt(x), _stream()), "maxpool2_fwd")
+    return y
+
+
+def maxpool2_bwd(x, dy, dx, accumulate=False):
+    _need_gpu(x, dy, dx)
+    N, D, H, W, Cc = x.shape
+    _ck(lib().msseg_maxpool2_bwd(_p(x), ld(x), _p(dy), ld(dy), _p(dx), ld(dx), N, D, H, W, Cc, int(accumulate), dt(x),
+                                 _stream()), "maxpool2_bwd")
+    return dx
+
+
+def to_channels_last(src: torch.Tensor, dst: torch.Tensor):
+    """src NCDHW contiguous -> dst [N, D, H, W, C] (dtype cast included)."""
+    _need_gpu(src, dst)
+    src = src.contiguous()
+    N, Cc = src.shape[0], src.shape[1]
+    S = src.numel() // (N * Cc)
+    _ck(lib().msseg_ncdhw_to_ndhwc(_p(src), dt(src), _p(dst), ld(dst), dt(dst), N, Cc, S, _stream()), "ncdhw_to_ndhwc")
+    return dst
+
+
+def to_channels_first(src: torch.Tensor, dst: torch.Tensor):
+    """src [N, D, H, W, C] (view allowed) -> dst NCDHW contiguous."""
+    _need_gpu(src, dst)
+    N, Cc = dst.shape[0], dst.shape[1]
+    S = dst.numel() // (N * Cc)
+    assert dst.is_contiguous()
+    _ck(lib().msseg_ndhwc_to_ncdhw(_p(src), ld(src), dt(src), _p(dst), dt(dst), N, Cc, S, _stream()), "ndhwc_to_ncdhw")
+    return dst
+
+
+def channel_sum(x, out, accumulate=False):
+    _need_gpu(x, out)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    _ck(lib().msseg_channel_sum(_p(x), ld(x), _p(out), rows, Cc, int(accumulate), dt(x), _stream()), "channel_sum")
+    return out
+
+
+def add(a, b, y):
+    _need_gpu(a, b, y)
+    Cc = a.shape[-1]
+    rows = a.numel() // Cc
+    _ck(lib().msseg_add(_p(a), ld(a), _p(b), ld(b), _p(y), ld(y), rows, Cc, dt(a), _stream()), "add")
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# loss / metric
+# --------------------------------------------------------------------------------------------
+def dice_ce_partials(logits, labels, n_cls, channels_last_ld=0, want_hard=False):
+    """logits: NCDHW (channels_last_ld == 0) or channels-last with voxel stride ld.  Returns (partial, hard)."""
+    _need_gpu(logits, labels)
+    N = logits.shape[0]
+    S = labels.numel() // N
+    partial = torch.zeros(N, n_cls, 4, dtype=torch.float32, device=logits.device)
+    hard = torch.zeros(N, n_cls, 3, dtype=torch.float32, device=logits.device) if want_hard else None
+    _ck(lib().msseg_dice_ce_partials(_p(logits), channels_last_ld, dt(logits), _p(labels), _LAB[labels.dtype],
+                                     _p(partial), _p(hard), N, S, n_cls, _stream()), "dice_ce_partials")
+    return partial, hard
+
+
+def dice_ce_finalize(partial, S, smooth_nr, smooth_dr):
+    N, Cc = partial.shape[0], partial.shape[1]
+    loss = torch.empty(3, dtype=torch.float32, device=partial.device)
+    _ck(lib().msseg_dice_ce_finalize(_p(partial), _p(loss), N, S, Cc, smooth_nr, smooth_dr, _stream()),
+        "dice_ce_finalize")
+    return loss
+
+
+def dice_ce_bwd(logits, labels, partial, gscale, dlogits, n_cls, smooth_nr, smooth_dr, ld_in=0, ld_out=0):
+    _need_gpu(logits, labels, partial, dlogits)
+    N = logits.shape[0]
+    S = labels.numel() // N
+    _ck(lib().msseg_dice_ce_bwd(_p(logits), ld_in, dt(logits), _p(labels), _LAB[labels.dtype], _p(partial),
+                                _p(gscale), _p(dlogits), ld_out, N, S, n_cls, smooth_nr, smooth_dr, _stream()),
+        "dice_ce_bwd")
+    return dlogits
+
+
+# --------------------------------------------------------------------------------------------
+# optimiser
+# --------------------------------------------------------------------------------------------
+def adamw_step(param, grad, exp_avg, exp_avg_sq, decay_mask, lr, beta1, beta2, eps, weight_decay, step,
+               grad_scale=None):
+    _need_gpu(param, grad, exp_avg, exp_avg_sq)
+    _ck(lib().msseg_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(decay_mask), param.numel(), lr,
+                               beta1, beta2, eps, weight_decay, step, _p(grad_scale), _stream()), "adamw_step")
+
+
+def sumsq(x, out):
+    _need_gpu(x, out)
+    _ck(lib().msseg_sumsq(_p(x), x.numel(), _p(out), _stream()), "sumsq")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# sliding window
+# --------------------------------------------------------------------------------------------
+def sw_blend(win, imp, out, cnt, start, channels_last_ld=0):
+    """win: [C, *roi] (NCDHW, ld 0) ; out: [C, *vol] fp32 ; cnt: [*vol] fp32."""
+    _need_gpu(win, imp, out, cnt)
+    Cc = out.shape[0]
+    VD, VH, VW = out.shape[1:]
+    RD, RH, RW = imp.shape
+    _ck(lib().msseg_sw_blend(_p(win), channels_last_ld, dt(win), _p(imp), _p(out), _p(cnt), Cc, VD, VH, VW, RD, RH, RW,
+                             int(start[0]), int(start[1]), int(start[2]), _stream()), "sw_blend")
+
+
+def sw_normalize(out, cnt):
+    _need_gpu(out, cnt)
+    _ck(lib().msseg_sw_normalize(_p(out), _p(cnt), out.shape[0], cnt.numel(), _stream()), "sw_normalize")
+    return out
+
+
+def sw_gather(vol, win, start, cval=0.0):
+    """vol: [C, *vol] fp32 ; win: [C, *roi] (dtype of win)."""
+    _need_gpu(vol, win)
+    Cc = vol.shape[0]
+    VD, VH, VW = vol.shape[1:]
+    RD, RH, RW = win.shape[1:]
+    _ck(lib().msseg_sw_gather(_p(vol), _p(win), dt(win), Cc, VD, VH, VW, RD, RH, RW, int(start[0]), int(start[1]),
+                              int(start[2]), float(cval), _stream()), "sw_gather")
+    return win

@@ -1,0 +1,214 @@
+"""Layer primitives with explicit forward/backward over the C ABI (``hip.py``).
+
+Activations are channels-last ``[N, D, H, W, C]`` tensors (possibly channel slices of a wider
+concat buffer) in the model's compute dtype (bf16 or fp32).  Parameters stay ordinary fp32
+``nn.Parameter``s in the torch layouts (state-dict compatible with MONAI / the reference); every
+forward repacks them into the MFMA operand images (cached while weights are unchanged).
+
+Each primitive returns what its backward needs in a small tuple; the model-level
+``torch.autograd.Function`` (see ``models/unet.py``) strings them together, so one autograd node
+covers the whole network and every buffer / accumulation is decided here, not by autograd.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import hip
+
+# bumped by optimisers that update parameters behind torch's back (FlatAdamW): invalidates packed weights
+weights_epoch = 0
+
+
+def bump_weights_epoch():
+    global weights_epoch
+    weights_epoch += 1
+
+
+class PackedCache:
+    """Packed-weight images of one parameter, rebuilt when the parameter changed."""
+
+    def __init__(self):
+        self._key = None
+        self._val = {}
+
+    def get(self, p: torch.Tensor, dtype, kind: str, builder):
+        key = (p.data_ptr(), p._version, weights_epoch, dtype, p.device)
+        if key != self._key:
+            self._key, self._val = key, {}
+        v = self._val.get(kind)
+        if v is None:
+            v = builder()
+            self._val[kind] = v
+        return v
+
+
+def _grad_buf(p: torch.nn.Parameter):
+    """(tensor to write the gradient into, accumulate?)"""
+    if p.grad is None:
+        p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
+        return p.grad, False
+    return p.grad, True
+
+
+def _empty_like_vol(x, C, dtype=None):
+    return torch.empty(x.shape[:-1] + (C,), dtype=dtype or x.dtype, device=x.device)
+
+
+class Conv3:
+    """3x3x3 s1 p1 convolution (+bias).  Few-input-channel layers go through the gather kernel."""
+
+    def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter]):
+        self.w, self.b = weight, bias
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.cache = PackedCache()
+
+    def _gather(self, dtype):
+        return self.cin % (8 if dtype == torch.bfloat16 else 4) != 0
+
+    def fwd(self, x, out=None):
+        dtype = x.dtype
+        y = out if out is not None else _empty_like_vol(x, self.cout)
+        if self._gather(dtype):
+            wp = self.cache.get(self.w, dtype, "g", lambda: hip.pack_conv_gather(self.w.detach(), dtype))
+            hip.conv3d_gather(x, wp, self.b, y, self.cin, self.cout, 3, 1, 1)
+        else:
+            wp = self.cache.get(self.w, dtype, "f", lambda: hip.pack_conv_k3(self.w.detach(), dtype))
+            hip.conv3d_k3(x, wp, self.b, y, self.cin, self.cout)
+        return y
+
+    def bwd(self, x, dy, need_dx=True, dx_out=None):
+        dtype = x.dtype
+        if self.w.requires_grad:
+            g, acc = _grad_buf(self.w)
+            if self._gather(dtype):
+                hip.conv3d_gather_wgrad(x, dy, g, self.cin, self.cout, 3, 1, 1, acc)
+            else:
+                hip.conv3d_k3_wgrad(x, dy, g, self.cin, self.cout, acc)
+        if self.b is not None and self.b.requires_grad:
+            g, acc = _grad_buf(self.b)
+            hip.channel_sum(dy, g, acc)
+        if not need_dx:
+            return None
+        if self._gather(dtype):
+            raise NotImplementedError("input gradient of a few-channel stem conv is never needed on this path")
+        wp = self.cache.get(self.w, dtype, "d", lambda: hip.pack_conv_k3(self.w.detach(), dtype, dgrad=True))
+        dx = dx_out if dx_out is not None else _empty_like_vol(dy, self.cin)
+        hip.conv3d_k3(dy, wp, None, dx, self.cout, self.cin)
+        return dx
+
+
+class Conv1:
+    """1x1x1 convolution (+bias).  `cin_pad`: the input tensor carries zero-padded channels up to cin_pad."""
+
+    def __init__(self, weight, bias):
+        self.w, self.b = weight, bias
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.cache = PackedCache()
+
+    def fwd(self, x, out=None):
+        dtype = x.dtype
+        y = out if out is not None else _empty_like_vol(x, self.cout)
+        wp = self.cache.get(self.w, dtype, "f", lambda: hip.pack_conv_k1(self.w.detach().reshape(self.cout, self.cin), dtype))
+        hip.conv3d_k1(x, wp, self.b, y, self.cin, self.cout)
+        return y
+
+    def bwd(self, x, dy, need_dx=True, dy_channels=None):
+        """dy may carry zero-padded channels (dy_channels = padded count, multiple of 8)."""
+        dtype = x.dtype
+        if self.w.requires_grad:
+            g, acc = _grad_buf(self.w)
+            hip.conv3d_k1_wgrad(x, dy[..., :self.cout], g, self.cin, self.cout, acc)
+        if self.b is not None and self.b.requires_grad:
+            g, acc = _grad_buf(self.b)
+            hip.channel_sum(dy[..., :self.cout], g, acc)
+        if not need_dx:
+            return None
+        wp = self.cache.get(self.w, dtype, "d",
+                            lambda: hip.pack_conv_k1(self.w.detach().reshape(self.cout, self.cin), dtype, dgrad=True))
+        dx = _empty_like_vol(dy, self.cin)
+        kpad = dy_channels if dy_channels is not None else self.cout
+        hip.conv3d_k1(dy if dy_channels is None else dy[..., :kpad], wp, None, dx, kpad, self.cin)
+        return dx
+
+
+class Deconv2:
+    """ConvTranspose3d k = s = 2 (+bias): [N,D,H,W,Cin] -> [N,2D,2H,2W,Cout]."""
+
+    def __init__(self, weight, bias):
+        self.w, self.b = weight, bias
+        self.cin, self.cout = weight.shape[0], weight.shape[1]
+        self.cache = PackedCache()
+
+    def fwd(self, x, out=None):
+        dtype = x.dtype
+        N, D, H, W, _ = x.shape
+        y = out if out is not None else torch.empty(N, 2 * D, 2 * H, 2 * W, self.cout, dtype=dtype, device=x.device)
+        wp = self.cache.get(self.w, dtype, "f", lambda: hip.pack_deconv(self.w.detach(), dtype))
+        hip.deconv_k2s2(x, wp, self.b, y, self.cin, self.cout)
+        return y
+
+    def bwd(self, x, dy, need_dx=True):
+        dtype = x.dtype
+        if self.w.requires_grad:
+            g, acc = _grad_buf(self.w)
+            hip.deconv_k2s2_wgrad(x, dy, g, self.cin, self.cout, acc)
+        if self.b is not None and self.b.requires_grad:
+            g, acc = _grad_buf(self.b)
+            hip.channel_sum(dy, g, acc)
+        if not need_dx:
+            return None
+        wp = self.cache.get(self.w, dtype, "d", lambda: hip.pack_deconv(self.w.detach(), dtype, bwd=True))
+        dx = torch.empty_like(x, memory_format=torch.contiguous_format)
+        hip.deconv_k2s2_bwd_data(dy, wp, dx, self.cin, self.cout)
+        return dx
+
+
+class InstNormAct:
+    """InstanceNorm3d(eps 1e-5) [+affine] [+residual] + LeakyReLU(slope); slope == 1 -> no activation."""
+
+    def __init__(self, gamma: Optional[torch.nn.Parameter], beta: Optional[torch.nn.Parameter], slope: float,
+                 eps: float = 1e-5):
+        self.gamma, self.beta, self.slope, self.eps = gamma, beta, float(slope), float(eps)
+
+    def fwd(self, y_raw, out=None, residual=None):
+        stats = hip.channel_stats(y_raw)
+        a = out if out is not None else torch.empty_like(y_raw, memory_format=torch.contiguous_format)
+        hip.instnorm_act_fwd(y_raw, stats, self.gamma, self.beta, a, self.slope, self.eps, residual)
+        return a, stats
+
+    def bwd(self, y_raw, stats, a, da, want_dres=False):
+        dy = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device)
+        dres = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device) if want_dres else None
+        red = hip.instnorm_act_bwd(y_raw, stats, self.gamma, a, da, dy, self.slope, self.eps, dres)
+        if self.gamma is not None and self.gamma.requires_grad:
+            g = red[..., 1].sum(0)
+            self.gamma.grad = g if self.gamma.grad is None else self.gamma.grad + g
+        if self.beta is not None and self.beta.requires_grad:
+            g = red[..., 0].sum(0)
+            self.beta.grad = g if self.beta.grad is None else self.beta.grad + g
+        return (dy, dres) if want_dres else dy
+
+
+class ConvNormAct:
+    """conv3x3x3 -> InstanceNorm -> LeakyReLU, the unit of BasicUNet's TwoConv."""
+
+    def __init__(self, conv: Conv3, norm: InstNormAct):
+        self.conv, self.norm = conv, norm
+
+    def fwd(self, x, out=None):
+        y = self.conv.fwd(x)
+        a, stats = self.norm.fwd(y, out)
+        return a, (x, y, stats, a)
+
+    def bwd(self, saved, da, need_dx=True):
+        x, y, stats, a = saved
+        dy = self.norm.bwd(y, stats, a, da)
+        return self.conv.bwd(x, dy, need_dx)
+
+
+def maxpool_fwd(x):
+    N, D, H, W, C = x.shape
+    y = torch.empty(N, D // 2, H // 2, W // 2, C, dtype=x.dtype, device=x.device)
+    return hip.maxpool2_fwd(x, y)

@@ -1,0 +1,204 @@
+"""3-D UNet (MONAI ``BasicUNet`` topology) on the HIP kernels.
+
+BASELINE.json configs 2-3 name "UNet base (MONAI BasicUNet) 1->3cls": features (32,32,64,128,256,32),
+LeakyReLU(0.1), InstanceNorm3d(affine=True), bias=True, deconv upsampling, skip FIRST in the concat
+(SURVEY.md 8(a) row A15).  The reference itself ships no UNet; ``build_model`` gains ``cfg.model in
+{'UNet','UNetSmall'}`` branches.  Module / parameter names follow MONAI's
+state-dict layout (``conv_0.conv_0.conv.weight``, ``upcat_4.upsample.deconv.weight``, ``final_conv.bias`` ...).
+
+The sub-modules below only HOLD parameters (with torch's default initialisation, which is what MONAI's
+layers use); the arithmetic is one ``torch.autograd.Function`` that runs the whole network forward and
+backward through ``layers.py`` -- concat buffers are written in place by their producers, the max-pool
+gradient is accumulated into the skip gradient, and parameter gradients land directly in ``.grad``.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import hip
+from ..layers import Conv1, Conv3, ConvNormAct, Deconv2, InstNormAct, maxpool_fwd
+
+UNET_FEATURES = {"UNet": (32, 32, 64, 128, 256, 32), "UNetSmall": (16, 16, 32, 64, 128, 16)}
+LOGIT_LD = 8  # channel stride of the internal logits / dlogits buffers (16-byte rows for both dtypes)
+
+
+class _ADN(nn.Sequential):
+    def __init__(self, ch):
+        super().__init__()
+        self.add_module("N", nn.InstanceNorm3d(ch, affine=True))
+
+
+class _ConvADN(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("conv", nn.Conv3d(cin, cout, 3, padding=1, bias=True))
+        self.add_module("adn", _ADN(cout))
+
+
+class _TwoConv(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("conv_0", _ConvADN(cin, cout))
+        self.add_module("conv_1", _ConvADN(cout, cout))
+
+
+class _Down(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("convs", _TwoConv(cin, cout))
+
+
+class _Up(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("deconv", nn.ConvTranspose3d(cin, cout, kernel_size=2, stride=2, bias=True))
+
+
+class _UpCat(nn.Module):
+    def __init__(self, in_chns, cat_chns, out_chns, halves=True):
+        super().__init__()
+        up = in_chns // 2 if halves else in_chns
+        self.upsample = _Up(in_chns, up)
+        self.convs = _TwoConv(cat_chns + up, out_chns)
+
+
+def _cna(m: _ConvADN, slope):
+    return ConvNormAct(Conv3(m.conv.weight, m.conv.bias), InstNormAct(m.adn.N.weight, m.adn.N.bias, slope))
+
+
+class UNet(nn.Module):
+    """``model((vol[B,C,D,H,W], crop_loc, affine)) -> logits[B,out,D,H,W]`` (fp32, NCDHW).
+
+    compute_dtype: torch.bfloat16 (speed) or torch.float32 (exact-fp32 MFMA path used for parity)."""
+
+    def __init__(self, in_channels=1, out_channels=2, features: Sequence[int] = UNET_FEATURES["UNet"],
+                 compute_dtype=torch.bfloat16, slope=0.1):
+        super().__init__()
+        f = tuple(features)
+        self.in_channels, self.out_channels, self.features = in_channels, out_channels, f
+        self.compute_dtype = compute_dtype
+        self.slope = slope
+        self.conv_0 = _TwoConv(in_channels, f[0])
+        self.down_1 = _Down(f[0], f[1])
+        self.down_2 = _Down(f[1], f[2])
+        self.down_3 = _Down(f[2], f[3])
+        self.down_4 = _Down(f[3], f[4])
+        self.upcat_4 = _UpCat(f[4], f[3], f[3])
+        self.upcat_3 = _UpCat(f[3], f[2], f[2])
+        self.upcat_2 = _UpCat(f[2], f[1], f[1])
+        self.upcat_1 = _UpCat(f[1], f[0], f[5], halves=False)
+        self.final_conv = nn.Conv3d(f[5], out_channels, kernel_size=1)
+        self._build_ops()
+
+    def _build_ops(self):
+        s = self.slope
+        self._enc = [(_cna(self.conv_0.conv_0, s), _cna(self.conv_0.conv_1, s))]
+        for d in (self.down_1, self.down_2, self.down_3, self.down_4):
+            self._enc.append((_cna(d.convs.conv_0, s), _cna(d.convs.conv_1, s)))
+        self._dec = []
+        for u in (self.upcat_4, self.upcat_3, self.upcat_2, self.upcat_1):
+            self._dec.append((Deconv2(u.upsample.deconv.weight, u.upsample.deconv.bias),
+                              _cna(u.convs.conv_0, s), _cna(u.convs.conv_1, s)))
+        self._final = Conv1(self.final_conv.weight, self.final_conv.bias)
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._build_ops()  # parameters were replaced (.to / .cuda): re-bind the op objects
+        return r
+
+    def forward(self, x_in):
+        vol = x_in[0] if isinstance(x_in, (tuple, list)) else x_in
+        if not vol.is_cuda:
+            raise RuntimeError("medicalsemseg_amd.UNet runs on the GPU only (no CPU fallback); "
+                               "the CPU oracle lives in oracle/ and is test infrastructure")
+        if any(int(d) % 16 for d in vol.shape[2:]):
+            raise ValueError(f"UNet needs spatial dims divisible by 16, got {tuple(vol.shape[2:])}")
+        params = [p for p in self.parameters()]
+        return _UNetFn.apply(self, vol, *params)
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net: UNet, vol, *params):
+        T = net.compute_dtype
+        N, Cin, D, H, W = vol.shape
+        dev = vol.device
+        f = net.features
+        need_grad = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        x = torch.empty(N, D, H, W, Cin, dtype=T, device=dev)
+        hip.to_channels_last(vol.float() if vol.dtype not in (torch.float32, torch.bfloat16) else vol, x)
+        saved = {"enc": [], "dec": []}
+        # concat buffers [skip | up] for the 4 decoder levels (level i uses encoder output i)
+        cat = []
+        for i in range(4):
+            sh = (N, D >> i, H >> i, W >> i)
+            up_ch = f[i + 1] // 2 if i > 0 else f[1]
+            cat.append(torch.empty(sh + (f[i] + up_ch,), dtype=T, device=dev))
+        cur = x
+        skips = []
+        for lvl, (c0, c1) in enumerate(net._enc):
+            if lvl > 0:
+                pooled_src = cur
+                cur = maxpool_fwd(cur)
+            a0, s0 = c0.fwd(cur)
+            out = cat[lvl][..., :f[lvl]] if lvl < 4 else None
+            a1, s1 = c1.fwd(a0, out)
+            saved["enc"].append((s0, s1))
+            skips.append(a1)
+            cur = a1
+        # decoder: levels 3..0
+        for j, (up, c0, c1) in enumerate(net._dec):
+            lvl = 3 - j
+            up_in = cur
+            up.fwd(up_in, cat[lvl][..., f[lvl]:])
+            a0, s0 = c0.fwd(cat[lvl])
+            a1, s1 = c1.fwd(a0)
+            saved["dec"].append((up_in, s0, s1))
+            cur = a1
+        logits_cl = torch.empty(N, D, H, W, LOGIT_LD, dtype=T, device=dev)
+        net._final.fwd(cur, logits_cl[..., :net.out_channels])
+        logits = torch.empty(N, net.out_channels, D, H, W, dtype=torch.float32, device=dev)
+        hip.to_channels_first(logits_cl[..., :net.out_channels], logits)
+        if need_grad:
+            ctx.net, ctx.saved, ctx.last, ctx.skips = net, saved, cur, skips
+        ctx.set_materialize_grads(False)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        net, saved = ctx.net, ctx.saved
+        n_in = 2 + len(list(net.parameters()))
+        if dlogits is None:
+            return (None,) * n_in
+        T = net.compute_dtype
+        f = net.features
+        N, C, D, H, W = dlogits.shape
+        dev = dlogits.device
+        dl = torch.zeros(N, D, H, W, LOGIT_LD, dtype=T, device=dev)
+        hip.to_channels_last(dlogits.contiguous(), dl[..., :C])
+        g = net._final.bwd(ctx.last, dl, True, dy_channels=LOGIT_LD)
+        skip_grads = [None] * 4
+        for j in range(3, -1, -1):  # decoder levels 0..3 in reverse order of execution
+            up, c0, c1 = net._dec[j]
+            lvl = 3 - j
+            up_in, s0, s1 = saved["dec"][j]
+            g = c1.bwd(s1, g, True)
+            dcat = c0.bwd(s0, g, True)
+            skip_grads[lvl] = dcat[..., :f[lvl]]
+            g = up.bwd(up_in, dcat[..., f[lvl]:], True)
+        # encoder, bottom-up
+        for lvl in range(4, -1, -1):
+            c0, c1 = net._enc[lvl]
+            s0, s1 = saved["enc"][lvl]
+            if lvl < 4:
+                # gradient of the skip (written by the decoder) + max-pool path from the level below
+                x_l = s1[3]
+                hip.maxpool2_bwd(x_l, g, skip_grads[lvl], accumulate=True)
+                g = skip_grads[lvl]
+            g = c1.bwd(s1, g, True)
+            g = c0.bwd(s0, g, need_dx=(lvl > 0))
+        ctx.saved = None
+        return (None,) * n_in

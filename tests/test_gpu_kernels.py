@@ -1,0 +1,331 @@
+"""GPU parity tests: every HIP kernel (through the C ABI / ctypes) against stock torch-CPU fp32 ops.
+
+Tolerances: fp32 path rtol 1e-4 on outputs (north_star's logits tolerance); bf16 path is compared with the
+same fp32 reference evaluated on bf16-rounded inputs/weights, to ~1 bf16 ulp of the output scale.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def cl(x_ncdhw, dtype, dev):
+    """NCDHW cpu -> channels-last gpu"""
+    return x_ncdhw.permute(0, 2, 3, 4, 1).contiguous().to(dev, dtype)
+
+
+def ncdhw(x_cl):
+    return x_cl.float().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def rnd(dtype, *ts):
+    """round tensors through the compute dtype (what the kernel will actually see)"""
+    out = [t.to(dtype).float() for t in ts]
+    return out if len(out) > 1 else out[0]
+
+
+def check(got, ref, dtype, what, scale=None):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    s = float(ref.abs().max()) if scale is None else scale
+    s = max(s, 1e-6)
+    tol = 2e-5 if dtype == torch.float32 else 6e-3
+    err = float((got - ref).abs().max()) / s
+    assert err < tol, f"{what}: max rel-to-scale error {err:.3e} (tol {tol})"
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,sp", [(32, 32, (16, 16, 16)), (64, 32, (32, 32, 32)), (32, 64, (12, 12, 12)),
+                                         (48, 48, (12, 12, 24)), (16, 16, (8, 8, 8)), (128, 256, (6, 6, 6)),
+                                         (96, 48, (6, 10, 18)), (8, 24, (5, 7, 9))])
+def test_conv3d_k3_fwd_dgrad_wgrad(dtype, cin, cout, sp):
+    from medicalsemseg_amd import hip
+    from medicalsemseg_amd.layers import Conv3
+    dev = _dev()
+    N = 2
+    x = gen(N, cin, *sp, seed=1)
+    w = gen(cout, cin, 3, 3, 3, seed=2, scale=(cin * 27) ** -0.5)
+    b = gen(cout, seed=3)
+    dy = gen(N, cout, *sp, seed=4)
+    xr, wr, dyr = rnd(dtype, x, w, dy)
+    xr.requires_grad_(True); wr.requires_grad_(True)
+    yref = F.conv3d(xr, wr, b, padding=1)
+    yref.backward(dyr)
+    wp = torch.nn.Parameter(w.to(dev)); bp = torch.nn.Parameter(b.to(dev))
+    op = Conv3(wp, bp)
+    xg = cl(x, dtype, dev)
+    y = op.fwd(xg)
+    check(ncdhw(y), yref.detach(), dtype, "conv3d_k3 fwd")
+    dyg = cl(dy, dtype, dev)
+    dx = op.bwd(xg, dyg, True)
+    check(ncdhw(dx), xr.grad, dtype, "conv3d_k3 dgrad")
+    check(wp.grad, wr.grad, dtype, "conv3d_k3 wgrad")
+    check(bp.grad, dyr.sum((0, 2, 3, 4)), dtype, "conv3d_k3 bias grad")
+    # accumulate path
+    op.bwd(xg, dyg, False)
+    check(wp.grad, 2 * wr.grad, dtype, "conv3d_k3 wgrad accumulate")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3d_k3_channel_slices(dtype):
+    """input and output as channel slices of wider (concat) buffers"""
+    from medicalsemseg_amd import hip
+    dev = _dev()
+    x = gen(1, 32, 8, 8, 16, seed=5)
+    w = gen(16, 32, 3, 3, 3, seed=6, scale=0.05)
+    xr, wr = rnd(dtype, x, w)
+    yref = F.conv3d(xr, wr, None, padding=1)
+    big_in = torch.zeros(1, 8, 8, 16, 64, dtype=dtype, device=dev)
+    big_in[..., 32:] = cl(x, dtype, dev)
+    big_out = torch.full((1, 8, 8, 16, 48), 7.0, dtype=dtype, device=dev)
+    wp = hip.pack_conv_k3(w.to(dev), dtype)
+    hip.conv3d_k3(big_in[..., 32:], wp, None, big_out[..., 16:32], 32, 16)
+    check(ncdhw(big_out[..., 16:32]), yref, dtype, "conv slice out")
+    assert float((big_out[..., :16].float() - 7).abs().max()) == 0 and float((big_out[..., 32:].float() - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,s,p,sp", [(1, 32, 3, 1, 1, (16, 16, 16)), (1, 48, 2, 2, 0, (12, 12, 12)),
+                                                (4, 16, 3, 1, 1, (8, 8, 8)), (2, 48, 2, 2, 0, (10, 6, 14))])
+def test_conv3d_gather(dtype, cin, cout, k, s, p, sp):
+    from medicalsemseg_amd import hip
+    dev = _dev()
+    N = 2
+    x = gen(N, cin, *sp, seed=1)
+    w = gen(cout, cin, k, k, k, seed=2, scale=(cin * k ** 3) ** -0.5)
+    b = gen(cout, seed=3)
+    xr, wr = rnd(dtype, x, w)
+    wr.requires_grad_(True)
+    yref = F.conv3d(xr, wr, b, stride=s, padding=p)
+    dy = gen(*yref.shape, seed=4)
+    dyr = rnd(dtype, dy)
+    yref.backward(dyr)
+    xg = cl(x, dtype, dev)
+    wp = hip.pack_conv_gather(w.to(dev), dtype)
+    y = torch.empty(N, *yref.shape[2:], cout, dtype=dtype, device=dev)
+    hip.conv3d_gather(xg, wp, b.to(dev), y, cin, cout, k, s, p)
+    check(ncdhw(y), yref.detach(), dtype, "gather fwd")
+    dw = torch.empty(cout, cin, k, k, k, device=dev)
+    hip.conv3d_gather_wgrad(xg, cl(dy, dtype, dev), dw, cin, cout, k, s, p)
+    check(dw, wr.grad, dtype, "gather wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,sp", [(32, 32, (8, 8, 8)), (256, 128, (3, 3, 3)), (96, 48, (6, 6, 6)), (48, 48, (4, 6, 10))])
+def test_deconv_k2s2(dtype, cin, cout, sp):
+    from medicalsemseg_amd.layers import Deconv2
+    dev = _dev()
+    N = 2
+    x = gen(N, cin, *sp, seed=1)
+    w = gen(cin, cout, 2, 2, 2, seed=2, scale=cin ** -0.5)
+    b = gen(cout, seed=3)
+    xr, wr = rnd(dtype, x, w)
+    xr.requires_grad_(True); wr.requires_grad_(True)
+    yref = F.conv_transpose3d(xr, wr, b, stride=2)
+    dy = gen(*yref.shape, seed=4)
+    dyr = rnd(dtype, dy)
+    yref.backward(dyr)
+    wp = torch.nn.Parameter(w.to(dev)); bp = torch.nn.Parameter(b.to(dev))
+    op = Deconv2(wp, bp)
+    xg = cl(x, dtype, dev)
+    y = op.fwd(xg)
+    check(ncdhw(y), yref.detach(), dtype, "deconv fwd")
+    dx = op.bwd(xg, cl(dy, dtype, dev), True)
+    check(ncdhw(dx), xr.grad, dtype, "deconv bwd data")
+    check(wp.grad, wr.grad, dtype, "deconv wgrad")
+    check(bp.grad, dyr.sum((0, 2, 3, 4)), dtype, "deconv bias grad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout", [(32, 3), (96, 48), (48, 14), (16, 2)])
+def test_conv3d_k1(dtype, cin, cout):
+    from medicalsemseg_amd.layers import Conv1
+    dev = _dev()
+    sp = (6, 10, 12)
+    x = gen(2, cin, *sp, seed=1)
+    w = gen(cout, cin, 1, 1, 1, seed=2, scale=cin ** -0.5)
+    b = gen(cout, seed=3)
+    xr, wr = rnd(dtype, x, w)
+    xr.requires_grad_(True); wr.requires_grad_(True)
+    yref = F.conv3d(xr, wr, b)
+    dy = gen(*yref.shape, seed=4)
+    dyr = rnd(dtype, dy)
+    yref.backward(dyr)
+    wp = torch.nn.Parameter(w.to(dev)); bp = torch.nn.Parameter(b.to(dev))
+    op = Conv1(wp, bp)
+    xg = cl(x, dtype, dev)
+    ld = ((cout + 7) // 8) * 8
+    ybuf = torch.zeros(2, *sp, ld, dtype=dtype, device=dev)
+    op.fwd(xg, ybuf[..., :cout])
+    check(ncdhw(ybuf[..., :cout]), yref.detach(), dtype, "k1 fwd")
+    dybuf = torch.zeros(2, *sp, ld, dtype=dtype, device=dev)
+    dybuf[..., :cout] = cl(dy, dtype, dev)
+    dx = op.bwd(xg, dybuf, True, dy_channels=ld)
+    check(ncdhw(dx), xr.grad, dtype, "k1 dgrad")
+    check(wp.grad, wr.grad, dtype, "k1 wgrad")
+    check(bp.grad, dyr.sum((0, 2, 3, 4)), dtype, "k1 bias grad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,affine,res,slope", [(32, True, False, 0.1), (48, False, True, 0.01), (48, False, False, 1.0),
+                                                 (20, True, True, 0.01)])
+def test_instnorm_act(dtype, C, affine, res, slope):
+    from medicalsemseg_amd.layers import InstNormAct
+    dev = _dev()
+    sp = (8, 8, 10)
+    x = gen(2, C, *sp, seed=1) * 2 + 0.5
+    r = gen(2, C, *sp, seed=2)
+    ga = torch.nn.Parameter((gen(C, seed=3) * 0.2 + 1).to(dev)) if affine else None
+    be = torch.nn.Parameter((gen(C, seed=4) * 0.2).to(dev)) if affine else None
+    xr, rr = rnd(dtype, x, r)
+    xr.requires_grad_(True); rr.requires_grad_(True)
+    gar = ga.detach().cpu().clone().requires_grad_(True) if affine else None
+    ber = be.detach().cpu().clone().requires_grad_(True) if affine else None
+    z = F.instance_norm(xr, weight=gar, bias=ber, eps=1e-5)
+    if res:
+        z = z + rr
+    yref = F.leaky_relu(z, slope) if slope != 1.0 else z
+    dy = gen(*yref.shape, seed=5)
+    dyr = rnd(dtype, dy)
+    yref.backward(dyr)
+    op = InstNormAct(ga, be, slope)
+    xg = cl(x, dtype, dev)
+    rg = cl(r, dtype, dev) if res else None
+    a, stats = op.fwd(xg, residual=rg)
+    check(ncdhw(a), yref.detach(), dtype, "instnorm fwd")
+    # the backward mask uses the stored (rounded) output: use the reference's own output sign in bf16
+    out = op.bwd(xg, stats, a, cl(dy, dtype, dev), want_dres=res)
+    dx = out[0] if res else out
+    check(ncdhw(dx), xr.grad, dtype, "instnorm dx", scale=float(xr.grad.abs().max()))
+    if res:
+        check(ncdhw(out[1]), rr.grad, dtype, "instnorm dres")
+    if affine:
+        check(ga.grad, gar.grad, dtype, "dgamma", scale=float(gar.grad.abs().max()) * (1 if dtype == torch.float32 else 4))
+        check(be.grad, ber.grad, dtype, "dbeta", scale=float(ber.grad.abs().max()) * (1 if dtype == torch.float32 else 4))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [32, 12])
+def test_maxpool2(dtype, C):
+    from medicalsemseg_amd import hip
+    dev = _dev()
+    x = gen(2, C, 8, 12, 16, seed=1)
+    xr = rnd(dtype, x).requires_grad_(True)
+    yref = F.max_pool3d(xr, 2)
+    dy = gen(*yref.shape, seed=2)
+    dyr = rnd(dtype, dy)
+    yref.backward(dyr)
+    xg = cl(x, dtype, dev)
+    y = torch.empty(2, 4, 6, 8, C, dtype=dtype, device=dev)
+    hip.maxpool2_fwd(xg, y)
+    check(ncdhw(y), yref.detach(), dtype, "maxpool fwd")
+    dx = torch.empty_like(xg)
+    hip.maxpool2_bwd(xg, cl(dy, dtype, dev), dx)
+    check(ncdhw(dx), xr.grad, dtype, "maxpool bwd")
+    base = cl(gen(2, C, 8, 12, 16, seed=3), dtype, dev)
+    acc = base.clone()
+    hip.maxpool2_bwd(xg, cl(dy, dtype, dev), acc, accumulate=True)
+    check(ncdhw(acc), ncdhw(base) + xr.grad, dtype, "maxpool bwd accumulate")
+
+
+@pytest.mark.parametrize("C,lab_dtype", [(3, torch.float32), (2, torch.int64), (14, torch.uint8)])
+def test_dice_ce(C, lab_dtype):
+    from medicalsemseg_amd.losses import DiceCELoss, dice_from_counts
+    from oracle.losses import dice_ce_loss, dice_metric
+    dev = _dev()
+    sp = (12, 10, 14)
+    logits = gen(2, C, *sp, seed=1) * 2
+    g = torch.Generator().manual_seed(2)
+    labels = torch.randint(0, C, (2, 1, *sp), generator=g)
+    labels[1][labels[1] == C - 1] = 0  # a class absent from sample 1 -> NaN dice there
+    lr = logits.clone().requires_grad_(True)
+    ref = dice_ce_loss(lr, labels.float(), 1e-5, 1e-5)
+    (ref * 3.0).backward()
+    crit = DiceCELoss(smooth_nr=1e-5, smooth_dr=1e-5)
+    lg = logits.to(dev).requires_grad_(True)
+    loss = crit(lg, labels.to(dev).to(lab_dtype))
+    (loss * 3.0).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), lr.grad.numpy(), rtol=1e-4, atol=1e-9)
+    score, nn_ = dice_from_counts(crit.last["hard"])
+    sref, nref = dice_metric(logits, labels)
+    np.testing.assert_allclose(score.cpu().numpy(), sref.numpy(), rtol=1e-6, equal_nan=True)
+    assert torch.equal(nn_.cpu(), nref)
+
+
+def test_sw_gather_blend():
+    from medicalsemseg_amd import hip
+    dev = _dev()
+    vol = gen(2, 20, 24, 28, seed=1)
+    out = torch.zeros(3, 20, 24, 28, device=dev)
+    cnt = torch.zeros(20, 24, 28, device=dev)
+    imp = gen(8, 8, 12, seed=2).abs() + 0.1
+    oref, cref = torch.zeros(3, 20, 24, 28), torch.zeros(20, 24, 28)
+    for i, st in enumerate([(0, 0, 0), (4, 8, 6), (12, 16, 16), (4, 8, 6)]):
+        w = gen(3, 8, 8, 12, seed=10 + i)
+        hip.sw_blend(w.to(dev), imp.to(dev), out, cnt, st)
+        sl = (slice(None), slice(st[0], st[0] + 8), slice(st[1], st[1] + 8), slice(st[2], st[2] + 12))
+        oref[sl] += imp * w
+        cref[sl[1:]] += imp
+    assert torch.equal(out.cpu(), oref) and torch.equal(cnt.cpu(), cref)   # same fp32 op order -> bit-exact
+    win = torch.empty(2, 8, 8, 12, device=dev)
+    hip.sw_gather(vol.to(dev), win, (14, 20, 20), cval=-3.0)
+    ref = torch.full((2, 8, 8, 12), -3.0)
+    ref[:, :6, :4, :8] = vol[:, 14:20, 20:24, 20:28]
+    assert torch.equal(win.cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_unet_small_fwd_bwd(dtype):
+    """whole UNetSmall forward + DiceCE + backward vs the oracle BasicUNet (same state dict)"""
+    from medicalsemseg_amd.losses import DiceCELoss
+    from medicalsemseg_amd.models.unet import UNET_FEATURES, UNet
+    from oracle.blocks import BasicUNet
+    from oracle.losses import dice_ce_loss
+    dev = _dev()
+    torch.manual_seed(0)
+    ref = BasicUNet(1, 2, UNET_FEATURES["UNetSmall"])
+    net = UNet(1, 2, UNET_FEATURES["UNetSmall"], compute_dtype=dtype)
+    missing = net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(dev)
+    x = gen(2, 1, 32, 32, 32, seed=13)
+    g = torch.Generator().manual_seed(14)
+    y = torch.randint(0, 2, (2, 1, 32, 32, 32), generator=g).float()
+    out_ref = ref(x)
+    loss_ref = dice_ce_loss(out_ref, y)
+    loss_ref.backward()
+    crit = DiceCELoss()
+    out = net((x.to(dev), None, None))
+    loss = crit(out, y.to(dev))
+    loss.backward()
+    if dtype == torch.float32:
+        np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+        assert abs(float(loss) - float(loss_ref)) < 1e-4
+        gtol = 2e-3
+    else:
+        err = float((out.detach().cpu() - out_ref.detach()).abs().max()) / float(out_ref.abs().max())
+        assert err < 0.06, f"bf16 logits drift {err}"
+        assert abs(float(loss) - float(loss_ref)) < 2e-2
+        gtol = 0.15
+    pr = dict(ref.named_parameters())
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        gr = pr[name].grad
+        denom = float(gr.abs().max()) + 1e-8
+        err = float((p.grad.cpu() - gr).abs().max()) / denom
+        if name.endswith("conv.bias") and "final" not in name:
+            continue  # conv bias before InstanceNorm: true gradient is exactly 0, both sides hold rounding noise
+        assert err < gtol, f"{name}: grad rel err {err:.3e}"
