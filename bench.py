@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Headline benchmark: 96^3 volumes/s of UNet (MONAI BasicUNet 1->3) forward + DiceCE + backward + AdamW,
+bf16, per-GPU batch 2 (BASELINE.json configs[1]; configs[2] under torchrun = weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md for the fields).  `--workload sliding_window` times the
+512^3 sliding-window inference loop instead (reported in DESIGN.md, not the headline line).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic work of BasicUNet(32,32,64,128,256,32) 1->3, one 96^3 sample
+UNET_FWD_GFLOP_PER_VOL = 252.4
+UNET_FWDBWD_GFLOP_PER_VOL = 757.0
+UNET_FWDBWD_GB_PER_VOL_BF16 = 2.06
+MFMA_PEAK_BF16_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_batch(batch, size, n_cls, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, 1, size, size, size, generator=g)
+    # three nested spheres -> non-degenerate Dice
+    ax = torch.linspace(-1, 1, size)
+    r = (ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2).sqrt()
+    y = torch.zeros(size, size, size)
+    for c in range(1, n_cls):
+        y[r < 0.9 * (n_cls - c) / (n_cls - 1)] = c
+    y = y[None, None].repeat(batch, 1, 1, 1, 1)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(batch, size, n_cls, budget_s=25.0):
+    """The CPU oracle (torch fp32, all host cores) on the same synthetic step; bounded sample."""
+    from oracle.blocks import BasicUNet
+    from oracle.losses import dice_ce_loss
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = BasicUNet(1, n_cls)
+    opt = torch.optim.AdamW(net.parameters(), lr=4e-4, betas=(0.9, 0.95), eps=1e-6)
+    x, y = synth_batch(batch, size, n_cls, "cpu", 13)
+    times = []
+    t_all = time.perf_counter()
+    for i in range(4):
+        t0 = time.perf_counter()
+        loss = dice_ce_loss(net(x), y)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s and i >= 1:
+            break
+    steady = times[1:] if len(times) > 1 else times
+    med = sorted(steady)[len(steady) // 2]
+    return {"value": round(batch / med, 4), "unit": "vol/s", "cores": cores, "kind": "port",
+            "sample": f"{len(steady)} timed step(s) (after 1 warm-up) of the same B={batch} {size}^3 fwd+DiceCE+bwd+AdamW "
+                      f"step, oracle/ BasicUNet fp32 on torch-CPU, median {med:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--size", type=int, default=96)
+    ap.add_argument("--classes", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
+    args = ap.parse_args()
+
+    from medicalsemseg_amd import hip, parallel
+    from medicalsemseg_amd.losses import DiceCELoss
+    from medicalsemseg_amd.models.unet import UNet
+    from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay
+
+    parallel.init_from_env()
+    world, rank = parallel.world_size(), parallel.rank()
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    hip.load_library()
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(13 + rank)
+    net = UNet(1, args.classes, compute_dtype=dtype).to(dev)
+    opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=4e-4, betas=(0.9, 0.95), eps=1e-6)
+    crit = DiceCELoss(smooth_nr=1e-5, smooth_dr=1e-5)
+    x, y = synth_batch(args.batch, args.size, args.classes, dev, 13 + rank)
+
+    def step():
+        out = net((x, None, None))
+        loss = crit(out, y)
+        loss.backward()
+        if world > 1:
+            parallel.all_reduce_flat_grads(opt.flat_grad)
+            opt._gscale.mul_(1.0 / world)
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        loss = step()
+    sync()
+    hip.TIMER.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    hip.TIMER.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_v = float(loss)
+
+    vols = args.batch * args.steps * world
+    value = vols / dt
+    res = {
+        "metric": "96^3 vols/sec fwd+bwd (train)", "value": round(value, 3), "unit": "vol/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"UNet base (MONAI BasicUNet 32-32-64-128-256-32) 1->{args.classes}cls, {args.size}^3 "
+                               f"patches, DiceCE + AdamW, per-GPU batch {args.batch}", "global_batch": args.batch * world,
+                   "parallelism": f"dp{world}", "final_loss": round(loss_v, 5)},
+    }
+    if rank == 0:
+        summ = hip.TIMER.summary()
+        k = summ.get("conv3d_k3_fwd")
+        if k:
+            tf = k["flops"] / (k["total_ms"] * 1e-3) / 1e12
+            peak = MFMA_PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            res["roofline"] = {"bound": "mfma", "kernel": "igemm_fwd_kernel (conv3d k3 fwd + dgrad)",
+                               "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                               "traffic": None, "launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
+                               "share_of_step": round(k["total_ms"] / (dt * 1e3), 3)}
+            w = summ.get("conv3d_k3_wgrad")
+            if w:
+                res["roofline"]["wgrad_tflops"] = round(w["flops"] / (w["total_ms"] * 1e-3) / 1e12, 2)
+                res["roofline"]["wgrad_share_of_step"] = round(w["total_ms"] / (dt * 1e3), 3)
+        res["model_tflops"] = round(value / world * UNET_FWDBWD_GFLOP_PER_VOL / 1e3, 2)
+        res["hbm_roofline_frac_algorithmic"] = round(value / world * UNET_FWDBWD_GB_PER_VOL_BF16 / HBM_PEAK_GBS, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.batch, args.size, args.classes)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -177,6 +177,7 @@ template <typename T>
 __global__ void sw_blend_kernel(const T* __restrict__ win, long long ld, const float* __restrict__ imp,
                                 float* __restrict__ out, float* __restrict__ cnt, int C, int VD, int VH, int VW,
                                 int RD, int RH, int RW, int z0, int y0, int x0) {
+#pragma clang fp contract(off)  // mul then add with two roundings, bit-identical to torch's `out[idx] += imp * seg`
     const long long R = (long long)RD * RH * RW, V = (long long)VD * VH * VW;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < R; i += (long long)gridDim.x * 256) {
         const int rx = (int)(i % RW), ry = (int)((i / RW) % RH), rz = (int)(i / ((long long)RW * RH));
@@ -184,7 +185,8 @@ __global__ void sw_blend_kernel(const T* __restrict__ win, long long ld, const f
         const float w = imp[i];
         for (int c = 0; c < C; ++c) {
             const float val = ld > 0 ? DT<T>::ld(win + i * ld + c) : DT<T>::ld(win + c * R + i);
-            out[c * V + v] += w * val;
+            const float prod = w * val;
+            out[c * V + v] = out[c * V + v] + prod;
         }
         cnt[v] += w;
     }

@@ -115,17 +115,26 @@ def dt(t: torch.Tensor) -> int:
 
 def ld(t: torch.Tensor) -> int:
     """voxel stride of a channels-last [..., C] tensor (possibly a channel slice of a wider buffer)."""
-    if t.stride(-1) != 1:
+    C = t.shape[-1]
+    if C > 1 and t.stride(-1) != 1:
         raise ValueError("channels-last tensor must have unit channel stride")
-    if t.dim() == 1:
-        return t.shape[0]
-    l = t.stride(-2) if t.shape[-2] > 1 else max(t.shape[-1], t.stride(-2))
-    # leading dims must be dense w.r.t. the voxel stride
-    exp = l
+    # voxel stride = stride of the innermost spatial dim that has extent > 1 (size-1 dims carry arbitrary strides)
+    l = None
+    exp = None
     for d in range(t.dim() - 2, -1, -1):
-        if t.shape[d] > 1 and t.stride(d) != exp:
-            raise ValueError(f"tensor is not a dense channels-last volume: shape {tuple(t.shape)} stride {t.stride()}")
-        exp *= t.shape[d]
+        if t.shape[d] > 1:
+            if l is None:
+                l = t.stride(d)
+                exp = l * t.shape[d]
+            else:
+                if t.stride(d) != exp:
+                    raise ValueError(f"tensor is not a dense channels-last volume: shape {tuple(t.shape)} "
+                                     f"stride {t.stride()}")
+                exp *= t.shape[d]
+    if l is None:
+        l = C
+    if l < C:
+        raise ValueError("voxel stride smaller than the channel count")
     return l
 
 
@@ -186,13 +195,51 @@ def pack_deconv(w: torch.Tensor, dtype, bwd=False, out=None):
 
 
 # --------------------------------------------------------------------------------------------
+# optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg)
+# --------------------------------------------------------------------------------------------
+class KernelTimer:
+    """Collects (start, end, flops, bytes) per launch of the kernels it is asked to watch."""
+
+    def __init__(self):
+        self.records = {}
+        self.enabled = False
+
+    def launch(self, key, flops, nbytes, fn):
+        if not self.enabled:
+            return fn()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        r = fn()
+        e1.record(torch.cuda.current_stream())
+        self.records.setdefault(key, []).append((e0, e1, flops, nbytes))
+        return r
+
+    def summary(self):
+        out = {}
+        for k, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+            out[k] = {"launches": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
+                      "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs)}
+        return out
+
+
+TIMER = KernelTimer()
+
+
+# --------------------------------------------------------------------------------------------
 # igemm forward-shaped ops.  x, y: [N, D, H, W, C] channels-last (views allowed)
 # --------------------------------------------------------------------------------------------
 def conv3d_k3(x, wp, bias, y, cin, cout):
     _need_gpu(x, wp, y)
     N, D, H, W = x.shape[:4]
-    _ck(lib().msseg_conv3d_k3_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, dt(x),
-                                  _stream()), "conv3d_k3_fwd")
+    nv = N * D * H * W
+    esz = x.element_size()
+
+    def go():
+        _ck(lib().msseg_conv3d_k3_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, dt(x),
+                                      _stream()), "conv3d_k3_fwd")
+    TIMER.launch("conv3d_k3_fwd", 2.0 * nv * 27 * cin * cout, nv * (cin + cout) * esz + 27 * cin * cout * esz, go)
     return y
 
 
@@ -252,8 +299,12 @@ def conv3d_k3_wgrad(x, dy, dw, cin, cout, accumulate=False):
     _need_gpu(x, dy, dw)
     N, D, H, W = x.shape[:4]
     ws = _wg_ws(cout, 27, cin, x.device)
-    _ck(lib().msseg_conv3d_k3_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), N, D, H, W, cin, cout, int(accumulate),
-                                    _p(ws), ws.numel(), dt(x), _stream()), "conv3d_k3_wgrad")
+    nv = N * D * H * W
+
+    def go():
+        _ck(lib().msseg_conv3d_k3_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), N, D, H, W, cin, cout, int(accumulate),
+                                        _p(ws), ws.numel(), dt(x), _stream()), "conv3d_k3_wgrad")
+    TIMER.launch("conv3d_k3_wgrad", 2.0 * nv * 27 * cin * cout, nv * (cin + cout) * x.element_size() + 27 * cin * cout * 4, go)
 
 
 def conv3d_k1_wgrad(x, dy, dw, cin, cout, accumulate=False):

@@ -127,7 +127,7 @@ class _UNetFn(torch.autograd.Function):
         N, Cin, D, H, W = vol.shape
         dev = vol.device
         f = net.features
-        need_grad = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        need_grad = any(ctx.needs_input_grad)
         x = torch.empty(N, D, H, W, Cin, dtype=T, device=dev)
         hip.to_channels_last(vol.float() if vol.dtype not in (torch.float32, torch.bfloat16) else vol, x)
         saved = {"enc": [], "dec": []}

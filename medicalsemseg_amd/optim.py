@@ -1,0 +1,127 @@
+"""Flat-buffer AdamW + gradient clipping + LR schedule for the hot path.
+
+* ``FlatAdamW``: every parameter becomes a view into ONE fp32 buffer, every gradient a view into another;
+  the optimiser step is a single fused HIP kernel (``msseg_adamw_step``) and -- under data parallelism --
+  the gradient exchange is ONE RCCL all-reduce of the flat gradient buffer (``parallel.py``).
+  Semantics follow ``torch.optim.AdamW(param_groups, lr, betas=(0.9, 0.95), eps=1e-6)`` with timm's
+  ``add_weight_decay`` grouping as wired at ``/root/reference/run_training.py:92-93`` (no decay for 1-D
+  parameters and ``.bias``).
+* ``LinearWarmupCosineAnnealingLR``: closed form of ``/root/reference/models/optimizers/lr_scheduler.py:93-168``
+  (stepped once per epoch, ``run_training.py:174``); pinned by ``tests/golden/lr_misc.npz``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, List
+
+import torch
+
+from . import hip, layers
+
+
+def add_weight_decay(model: torch.nn.Module, weight_decay=1e-5, skip_list=()):
+    """timm.optim.optim_factory.add_weight_decay: 1-D params and *.bias get no decay."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.ndim <= 1 or name.endswith(".bias") or name in skip_list:
+            no_decay.append(p)
+        else:
+            decay.append(p)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.95), eps=1e-6, weight_decay=0.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        ps: List[torch.nn.Parameter] = [p for g in self.param_groups for p in g["params"]]
+        if not ps:
+            raise ValueError("no parameters")
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdamW runs on the GPU only (no CPU fallback)")
+        wds = {g["weight_decay"] for g in self.param_groups if g["weight_decay"] != 0.0}
+        if len(wds) > 1:
+            raise ValueError("FlatAdamW supports one non-zero weight_decay value")
+        self._wd = wds.pop() if wds else 0.0
+        n = sum(p.numel() for p in ps)
+        pad = (-n) % 4
+        self.flat_param = torch.zeros(n + pad, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n + pad, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.decay_mask = torch.zeros(n + pad, dtype=torch.uint8, device=dev)
+        self._views = []
+        off = 0
+        with torch.no_grad():
+            for g in self.param_groups:
+                for p in g["params"]:
+                    k = p.numel()
+                    self.flat_param[off:off + k].copy_(p.detach().reshape(-1))
+                    p.data = self.flat_param[off:off + k].view(p.shape)
+                    gv = self.flat_grad[off:off + k].view(p.shape)
+                    self._views.append((p, gv))
+                    if g["weight_decay"] != 0.0:
+                        self.decay_mask[off:off + k] = 1
+                    off += k
+        self._n = n
+        self._step = 0
+        self._gscale = torch.ones(1, dtype=torch.float32, device=dev)
+        self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.attach_grads()
+
+    def attach_grads(self):
+        """(re)bind every .grad to its slice of the flat gradient buffer (kernels then write in place)."""
+        for p, gv in self._views:
+            if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+                if p.grad is not None:
+                    gv.copy_(p.grad)
+                p.grad = gv
+
+    def zero_grad(self, set_to_none: bool = False):
+        # gradients are overwritten/accumulated in place in the flat buffer: zero it and keep the views bound
+        self.flat_grad.zero_()
+        self.attach_grads()
+
+    def grad_norm(self) -> torch.Tensor:
+        self._sq.zero_()
+        hip.sumsq(self.flat_grad, self._sq)
+        return self._sq.sqrt()
+
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_ semantics, folded into the step as a gradient scale (no extra pass)."""
+        total = self.grad_norm()
+        self._gscale.copy_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+        return total
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self.attach_grads()
+        self._step += 1
+        lr = self.param_groups[0]["lr"]
+        b1, b2 = self.param_groups[0]["betas"]
+        eps = self.param_groups[0]["eps"]
+        hip.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.decay_mask, lr, b1, b2, eps,
+                       self._wd, self._step, self._gscale)
+        self._gscale.fill_(1.0)
+        layers.bump_weights_epoch()
+        return None
+
+
+class LinearWarmupCosineAnnealingLR(torch.optim.lr_scheduler._LRScheduler):
+    def __init__(self, optimizer, warmup_epochs: int, max_epochs: int, warmup_start_lr: float = 0.0,
+                 eta_min: float = 0.0, last_epoch: int = -1):
+        self.warmup_epochs, self.max_epochs = warmup_epochs, max_epochs
+        self.warmup_start_lr, self.eta_min = warmup_start_lr, eta_min
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        e = self.last_epoch
+        if e < self.warmup_epochs:
+            return [self.warmup_start_lr + e * (b - self.warmup_start_lr) / max(self.warmup_epochs - 1, 1)
+                    for b in self.base_lrs]
+        return [self.eta_min + 0.5 * (b - self.eta_min) *
+                (1 + math.cos(math.pi * (e - self.warmup_epochs) / (self.max_epochs - self.warmup_epochs)))
+                for b in self.base_lrs]
