@@ -63,7 +63,9 @@ int msseg_cout_block(int M);
  * (models/segmentors/swin_unetr.py:73-128) and, with dgrad-packed weights, its input gradient.
  * Requires Cin % (16/sizeof(elem)) == 0. */
 int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
-                        int N, int D, int H, int W, int Cin, int Cout, int dtype, msseg_stream_t stream);
+                        int N, int D, int H, int W, int Cin, int Cout, float* stats /* nullable: fused InstanceNorm
+                        statistics stats[n][cout][2] = (sum, sum of squares) of y as stored; needs N <= 8 */,
+                        void* scratch, size_t scratch_bytes, int dtype, msseg_stream_t stream);
 /* Conv3d k=1 (UnetResBlock.conv3, UnetOutBlock models/segmentors/swin_unetr.py:130, BasicUNet final_conv). */
 int msseg_conv3d_k1_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                         long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
@@ -100,19 +102,26 @@ int msseg_deconv_k2s2_wgrad(const void* x, long long ldx, const void* dy, long l
 /* ---------------------------------------------------------------------------------------------
  * Normalisation / activation / pooling / layout (HBM-bound, one pass each).
  * ------------------------------------------------------------------------------------------- */
-/* stats[n][c][0..1] += (sum, sum of squares) over the S voxels of sample n (caller zero-fills). */
-int msseg_channel_stats(const void* x, long long ldx, float* stats, int N, long long S, int C, int dtype,
-                        msseg_stream_t stream);
+/* Reductions are two-stage and deterministic: blocks write partials into `scratch`, the last block to arrive
+ * (agent-scope release/acquire on a counter at scratch[0]) sums them in a fixed order.  `scratch` must be
+ * 256-byte aligned, at least msseg_reduce_scratch_bytes() long and ZERO-INITIALISED ONCE by the caller (kernels
+ * leave the counter at zero); kernels sharing one scratch must be ordered on one stream. */
+size_t msseg_reduce_scratch_bytes(void);
+/* stats[n][c][0..1] = (sum, sum of squares) over the S voxels of sample n. */
+int msseg_channel_stats(const void* x, long long ldx, float* stats, int N, long long S, int C, void* scratch,
+                        size_t scratch_bytes, int dtype, msseg_stream_t stream);
 /* InstanceNorm3d(eps) [+affine] [+residual] + LeakyReLU(slope) in one pass (slope 1.0 = identity):
  * y = lrelu((x-mean)*rstd*gamma+beta + residual).  nn.InstanceNorm3d + nn.LeakyReLU of UnetResBlock /
  * TwoConv. */
 int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
                            const void* residual, long long ldr, void* y, long long ldy, int N, long long S, int C,
                            float eps, float slope, int dtype, msseg_stream_t stream);
-/* backward, pass 1: red[n][c] += (sum dz, sum dz*xhat), dz = dy * lrelu'(y) (sign taken from the output y). */
+/* backward, pass 1: red[n][c] = (sum dz, sum dz*xhat), dz = dy * lrelu'(y) (sign taken from the output y);
+ * optional affine gradients dbeta[c] (+)= sum_n red[n][c][0], dgamma[c] (+)= sum_n red[n][c][1]. */
 int msseg_instnorm_act_bwd_reduce(const void* x, long long ldx, const float* stats, const void* y, long long ldy,
-                                  const void* dy, long long lddy, float* red, int N, long long S, int C, float eps,
-                                  float slope, int dtype, msseg_stream_t stream);
+                                  const void* dy, long long lddy, float* red, float* dgamma, float* dbeta,
+                                  int accumulate, int N, long long S, int C, float eps, float slope, void* scratch,
+                                  size_t scratch_bytes, int dtype, msseg_stream_t stream);
 /* backward, pass 2: dx = rstd*gamma*(dz - red0/S - xhat*red1/S); dres (optional) = dz. */
 int msseg_instnorm_act_bwd_apply(const void* x, long long ldx, const float* stats, const float* gamma, const void* y,
                                  long long ldy, const void* dy, long long lddy, const float* red, void* dx,
@@ -129,8 +138,8 @@ int msseg_ncdhw_to_ndhwc(const void* src, int src_dtype, void* dst, long long ld
 int msseg_ndhwc_to_ncdhw(const void* src, long long lds, int src_dtype, void* dst, int dst_dtype, int N, int C,
                          long long S, msseg_stream_t stream);
 /* out[c] (+)= sum over rows of x[row][c] (bias gradients). */
-int msseg_channel_sum(const void* x, long long ldx, float* out, long long rows, int C, int accumulate, int dtype,
-                      msseg_stream_t stream);
+int msseg_channel_sum(const void* x, long long ldx, float* out, long long rows, int C, int accumulate, void* scratch,
+                      size_t scratch_bytes, int dtype, msseg_stream_t stream);
 /* y = a + b (elementwise over rows x C with strides) */
 int msseg_add(const void* a, long long lda, const void* b, long long ldb, void* y, long long ldy, long long rows,
               int C, int dtype, msseg_stream_t stream);

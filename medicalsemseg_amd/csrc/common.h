@@ -73,5 +73,31 @@ MSSEG_DEVFN float wave_sum(float v) {
     return v;
 }
 
+// ---- deterministic grid-wide reductions: "last block finalises" -----------------------------------
+// Every block stores its partial results with plain stores, then calls this.  Exactly one block (the
+// last to arrive) gets `true` and may read all partials with plain loads.  Placement-independent
+// agent-scope release/acquire (cdna_hip_programming.md Guideline 16); the counter is left at zero.
+MSSEG_DEVFN bool grid_last_block(unsigned int* counter, unsigned int total_blocks, int* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (prev == total_blocks - 1u) ? 1 : 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *lds_flag = last;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
+
+#define MSSEG_SCRATCH_COUNTER_BYTES 256
+#define MSSEG_STATS_NMAX 8
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

@@ -85,23 +85,64 @@ inline RowMap row_map(int C, int width) {
 // ---------------------------------------------------------------------------------------------------------
 // channel statistics: stats[n][c][0..1] += (sum x, sum x^2)
 // ---------------------------------------------------------------------------------------------------------
+// Finalise per-channel reductions in the last block: `nper` values per (n, c); partials laid out
+// ws[(n * nblk + b) * C * nper + c * nper + k].  MODE_OUT 0: out[n][c][k] = sum_b (statistics);
+// 1: out[c] (+)= sum_{n,b} (channel sums); 2: red[n][c][k] = sum_b and dparam_k[c] (+)= sum_n red[n][c][k].
+MSSEG_DEVFN void finalize_channels(const float* ws, int N, int nblk, int C, int nper, int mode, float* out,
+                                   float* dp0, float* dp1, int accumulate) {
+    constexpr int PARTS = 4;
+    const int sub = threadIdx.x % PARTS;
+    const int nout = C * nper;
+    const long long blk = (long long)C * nper;
+    for (int base = 0; base < nout; base += 256 / PARTS) {
+        const int o = base + threadIdx.x / PARTS;
+        const bool ok = o < nout;
+        float tot = 0.f;
+        for (int n = 0; n < N; ++n) {
+            float s = 0.f;
+            if (ok) {
+                const float* src = ws + (long long)n * nblk * blk + o;
+#pragma unroll 8
+                for (int bb = sub; bb < nblk; bb += PARTS) s += src[(long long)bb * blk];
+            }
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if (ok && sub == 0 && mode != 1) out[(long long)n * blk + o] = s;
+            tot += s;
+        }
+        if (ok && sub == 0) {
+            if (mode == 1) {
+                out[o] = accumulate ? out[o] + tot : tot;
+            } else if (mode == 2) {
+                const int c = o / nper, k = o % nper;
+                float* dp = (k == 0) ? dp0 : dp1;
+                if (dp) dp[c] = accumulate ? dp[c] + tot : tot;
+            }
+        }
+    }
+}
+
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, long long ldx, float* stats,
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, long long ldx, float* out,
                                                             long long S, int C, int groups, int rows_par,
-                                                            long long rows_per_block, int nacc) {
+                                                            long long rows_per_block, int nacc, int accumulate,
+                                                            float* ws, unsigned int* counter) {
     constexpr int W = VEC ? DT<T>::EPC : 1;
     __shared__ float red[256 * 2 * (VEC ? DT<T>::EPC : 1)];
+    __shared__ int lflag;
     const int n = blockIdx.y;
     const int g = threadIdx.x % groups, rl = threadIdx.x / groups;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > S) r1 = S;
     const T* xn = x + (long long)n * S * ldx;
+    float* wsb = ws + ((long long)n * gridDim.x + blockIdx.x) * C * nacc;
     for (int gg = g; gg * W < C; gg += groups) {
         float s[W], s2[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) s[e] = s2[e] = 0.f;
         if (rl < rows_par) {
+#pragma unroll 4
             for (long long r = r0 + rl; r < r1; r += rows_par) {
                 if constexpr (VEC) {
                     Chunk<T> c;
@@ -114,7 +155,6 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
                 }
             }
         }
-        // reduce over the rows_par threads that share channel group gg
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < W; ++e) {
@@ -131,34 +171,43 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
                     b += red[((k * groups + g) * W + e) * 2 + 1];
                 }
                 const int c = gg * W + e;
-                if (nacc == 2) {
-                    atomicAdd(&stats[((long long)n * C + c) * 2 + 0], a);
-                    atomicAdd(&stats[((long long)n * C + c) * 2 + 1], b);
-                } else {
-                    atomicAdd(&stats[c], a);  // channel_sum mode: single accumulator per channel, n ignored
-                }
+                wsb[c * nacc + 0] = a;
+                if (nacc == 2) wsb[c * nacc + 1] = b;
             }
         }
     }
+    if (grid_last_block(counter, gridDim.x * gridDim.y, &lflag))
+        finalize_channels(ws, gridDim.y, gridDim.x, C, nacc, nacc == 2 ? 0 : 1, out, nullptr, nullptr, accumulate);
+}
+
+inline long long reduce_blocks(long long S, int rows_par, int N, int C, int nper) {
+    long long blocks = ceil_div_ll(S, (long long)rows_par * 8);
+    long long cap = (long long)msseg_num_cus() * 8 / (N > 0 ? N : 1) + 1;
+    const long long fit = (long long)(((size_t)16 << 20) / ((size_t)N * C * nper * 4));
+    if (cap > fit) cap = fit;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return blocks;
 }
 
 template <typename T>
-int launch_stats(const void* x, long long ldx, float* stats, int N, long long S, int C, int nacc, hipStream_t st) {
+int launch_stats(const void* x, long long ldx, float* out, int N, long long S, int C, int nacc, int accumulate,
+                 void* scratch, hipStream_t st) {
     const bool vec = vec_ok(x, ldx, C, sizeof(T));
     const RowMap m = row_map(C, vec ? DT<T>::EPC : 1);
-    long long blocks = ceil_div_ll(S, (long long)m.rows_par * 16);
-    const long long cap = (long long)msseg_num_cus() * 8 / (N > 0 ? N : 1) + 1;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
+    if (ceil_div(C, vec ? DT<T>::EPC : 1) > 256) MSSEG_FAIL(MSSEG_EINVAL, "channel reduction: too many channels (%d)", C);
+    long long blocks = reduce_blocks(S, m.rows_par, N, C, nacc);
     const long long rpb = ceil_div_ll(S, blocks);
     blocks = ceil_div_ll(S, rpb);
     dim3 grid((unsigned)blocks, N);
+    unsigned int* counter = (unsigned int*)scratch;
+    float* ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
     if (vec)
-        hipLaunchKernelGGL((channel_stats_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x, ldx, stats, S, C,
-                           m.groups, m.rows_par, rpb, nacc);
+        hipLaunchKernelGGL((channel_stats_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x, ldx, out, S, C,
+                           m.groups, m.rows_par, rpb, nacc, accumulate, ws, counter);
     else
-        hipLaunchKernelGGL((channel_stats_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x, ldx, stats, S, C,
-                           m.groups, m.rows_par, rpb, nacc);
+        hipLaunchKernelGGL((channel_stats_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x, ldx, out, S, C,
+                           m.groups, m.rows_par, rpb, nacc, accumulate, ws, counter);
     MSSEG_CHECK_LAUNCH("channel_stats");
     return MSSEG_OK;
 }
@@ -177,6 +226,7 @@ struct NormParams {
     void* dres; long long lddres;
     long long S; int C; float eps, slope;
     long long rows_per_block; int groups, rows_par;
+    float* ws; unsigned int* counter; float* dgamma; float* dbeta; int accumulate;
 };
 
 MSSEG_DEVFN void mean_rstd(const float* stats, int n, int C, int c, long long S, float eps, float& mean, float& rstd) {
@@ -193,6 +243,7 @@ template <typename T, bool VEC, int MODE>
 __global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
     constexpr int W = VEC ? DT<T>::EPC : 1;
     __shared__ float red[(MODE == 1) ? 256 * 2 * W : 1];
+    __shared__ int lflag;
     const int n = blockIdx.y;
     const int g = threadIdx.x % p.groups, rl = threadIdx.x / p.groups;
     const long long r0 = (long long)blockIdx.x * p.rows_per_block;
@@ -223,6 +274,7 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
             }
         }
         if (rl < p.rows_par) {
+#pragma unroll 4
             for (long long r = r0 + rl; r < r1; r += p.rows_par) {
                 float xv[W], o[W], yv[W], dv[W];
                 if constexpr (VEC) {
@@ -316,21 +368,25 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
                         b += red[((k * p.groups + g) * W + e) * 2 + 1];
                     }
                     const int c = gg * W + e;
-                    atomicAdd(&p.red[((long long)n * p.C + c) * 2 + 0], a);
-                    atomicAdd(&p.red[((long long)n * p.C + c) * 2 + 1], b);
+                    float* wsb = p.ws + ((long long)n * gridDim.x + blockIdx.x) * p.C * 2;
+                    wsb[c * 2 + 0] = a;
+                    wsb[c * 2 + 1] = b;
                 }
             }
         }
+    }
+    if constexpr (MODE == 1) {
+        // red[n][c] = (sum dz, sum dz*xhat); dbeta = sum_n red0, dgamma = sum_n red1
+        if (grid_last_block(p.counter, gridDim.x * gridDim.y, &lflag))
+            finalize_channels(p.ws, gridDim.y, gridDim.x, p.C, 2, 2, p.red, p.dbeta, p.dgamma, p.accumulate);
     }
 }
 
 template <typename T, int MODE> int launch_norm(NormParams& p, int N, bool vec, hipStream_t st) {
     const RowMap m = row_map(p.C, vec ? DT<T>::EPC : 1);
+    if (ceil_div(p.C, vec ? DT<T>::EPC : 1) > 256) MSSEG_FAIL(MSSEG_EINVAL, "instnorm: too many channels (%d)", p.C);
     p.groups = m.groups; p.rows_par = m.rows_par;
-    long long blocks = ceil_div_ll(p.S, (long long)m.rows_par * 8);
-    const long long cap = (long long)msseg_num_cus() * 16 / (N > 0 ? N : 1) + 1;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
+    long long blocks = reduce_blocks(p.S, m.rows_par, N, p.C, 2);
     p.rows_per_block = ceil_div_ll(p.S, blocks);
     blocks = ceil_div_ll(p.S, p.rows_per_block);
     dim3 grid((unsigned)blocks, N);
@@ -550,20 +606,29 @@ int msseg_pack_weights(const float* src, void* dst, int dtype, int M, int M0, in
     return MSSEG_OK;
 }
 
-int msseg_channel_stats(const void* x, long long ldx, float* stats, int N, long long S, int C, int dtype,
-                        msseg_stream_t stream) {
-    if (!x || !stats || N < 1 || S < 1 || C < 1 || ldx < C) MSSEG_FAIL(MSSEG_EINVAL, "channel_stats: bad args");
-    DISPATCH_T(dtype, return launch_stats<float>(x, ldx, stats, N, S, C, 2, (hipStream_t)stream),
-               return launch_stats<bf16_t>(x, ldx, stats, N, S, C, 2, (hipStream_t)stream));
+size_t msseg_reduce_scratch_bytes(void) { return ((size_t)16 << 20) + MSSEG_SCRATCH_COUNTER_BYTES; }
+
+static int scratch_ok(const void* scratch, size_t bytes, const char* who) {
+    if (!scratch || ((uintptr_t)scratch & 255) || bytes < msseg_reduce_scratch_bytes())
+        MSSEG_FAIL(MSSEG_EWORKSPACE, "%s: needs a zero-initialised, 256-byte aligned scratch of %zu bytes", who,
+                   msseg_reduce_scratch_bytes());
+    return MSSEG_OK;
 }
 
-int msseg_channel_sum(const void* x, long long ldx, float* out, long long rows, int C, int accumulate, int dtype,
-                      msseg_stream_t stream) {
+int msseg_channel_stats(const void* x, long long ldx, float* stats, int N, long long S, int C, void* scratch,
+                        size_t scratch_bytes, int dtype, msseg_stream_t stream) {
+    if (!x || !stats || N < 1 || S < 1 || C < 1 || ldx < C) MSSEG_FAIL(MSSEG_EINVAL, "channel_stats: bad args");
+    if (int rc = scratch_ok(scratch, scratch_bytes, "channel_stats")) return rc;
+    DISPATCH_T(dtype, return launch_stats<float>(x, ldx, stats, N, S, C, 2, 0, scratch, (hipStream_t)stream),
+               return launch_stats<bf16_t>(x, ldx, stats, N, S, C, 2, 0, scratch, (hipStream_t)stream));
+}
+
+int msseg_channel_sum(const void* x, long long ldx, float* out, long long rows, int C, int accumulate, void* scratch,
+                      size_t scratch_bytes, int dtype, msseg_stream_t stream) {
     if (!x || !out || rows < 1 || C < 1 || ldx < C) MSSEG_FAIL(MSSEG_EINVAL, "channel_sum: bad args");
-    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, (hipStream_t)stream) != hipSuccess)
-        MSSEG_FAIL(MSSEG_ELAUNCH, "channel_sum: memset failed");
-    DISPATCH_T(dtype, return launch_stats<float>(x, ldx, out, 1, rows, C, 1, (hipStream_t)stream),
-               return launch_stats<bf16_t>(x, ldx, out, 1, rows, C, 1, (hipStream_t)stream));
+    if (int rc = scratch_ok(scratch, scratch_bytes, "channel_sum")) return rc;
+    DISPATCH_T(dtype, return launch_stats<float>(x, ldx, out, 1, rows, C, 1, accumulate, scratch, (hipStream_t)stream),
+               return launch_stats<bf16_t>(x, ldx, out, 1, rows, C, 1, accumulate, scratch, (hipStream_t)stream));
 }
 
 int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
@@ -580,10 +645,15 @@ int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, con
 }
 
 int msseg_instnorm_act_bwd_reduce(const void* x, long long ldx, const float* stats, const void* y, long long ldy,
-                                  const void* dy, long long lddy, float* red, int N, long long S, int C, float eps,
-                                  float slope, int dtype, msseg_stream_t stream) {
+                                  const void* dy, long long lddy, float* red, float* dgamma, float* dbeta,
+                                  int accumulate, int N, long long S, int C, float eps, float slope, void* scratch,
+                                  size_t scratch_bytes, int dtype, msseg_stream_t stream) {
     if (!x || !stats || !y || !dy || !red) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_bwd_reduce: null pointer");
+    if (int rc = scratch_ok(scratch, scratch_bytes, "instnorm_act_bwd_reduce")) return rc;
     NormParams p{};
+    p.counter = (unsigned int*)scratch;
+    p.ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+    p.dgamma = dgamma; p.dbeta = dbeta; p.accumulate = accumulate;
     p.x = x; p.ldx = ldx; p.stats = stats; p.y = (void*)y; p.ldy = ldy; p.dy = dy; p.lddy = lddy; p.red = red;
     p.S = S; p.C = C; p.eps = eps; p.slope = slope;
     const int esz = dtype == MSSEG_F32 ? 4 : 2;

@@ -39,6 +39,9 @@ struct IgemmParams {
     int cin, k, s, p;    // gather: real Cin, kernel, stride, pad
     int creal;           // deconv modes: real channel count of the fine tensor
     int vec_store;       // y / ldy allow 4-element vector stores
+    float* stats;        // optional fused per-(n, cout) (sum, sum of squares) of the stored output
+    float* stats_ws;     // scratch partials
+    unsigned int* counter;
 };
 
 template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT>
@@ -55,7 +58,9 @@ struct IgemmCfg {
     static constexpr int PLANE = ((HV * 16 + 255) / 256) * 256;
     static constexpr int A_BYTES = ((4 * PLANE + 64 + 255) / 256) * 256;
     static constexpr int B_BYTES = NTAPS * 4 * COUTB * 16;
-    static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
+    static constexpr int STAT_FLOATS = MSSEG_STATS_NMAX * COUTB * 2;
+    static constexpr int STAT_BYTES = (EPI == EPI_STORE) ? STAT_FLOATS * 4 + 256 : 0;
+    static constexpr int LDS_BYTES = A_BYTES + B_BYTES + STAT_BYTES;
     static_assert(TV % (16 * WAVES) == 0, "tile must split into 16-voxel MFMA tiles per wave");
 };
 
@@ -88,6 +93,11 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
     }
     const int bbase = (q * COUTB + r) * 16;
     int kb_loaded = -1;
+    float* spart = (float*)(smem + C::A_BYTES + C::B_BYTES);
+    const bool do_stats = (EPI == EPI_STORE) && p.stats != nullptr;
+    if (do_stats) {
+        for (int i = tid; i < C::STAT_FLOATS; i += NTHREADS) spart[i] = 0.f;
+    }
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         int t = tile;
@@ -185,6 +195,11 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
             }
         }
         // ---------------- epilogue ----------------
+        float st[NT][4], st2[NT][4];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[j][e] = st2[j][e] = 0.f;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int v = (wave * MT + m) * 16 + r;
@@ -226,8 +241,74 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
                     }
                     store4<T>(dst, o);
                 } else {
-                    for (int e = 0; e < 4 && co + e < p.M; ++e)
-                        DT<T>::st(dst + e, o[e] + (p.bias ? p.bias[cbase + e] : 0.f));
+                    for (int e = 0; e < 4 && co + e < p.M; ++e) {
+                        o[e] += (p.bias ? p.bias[cbase + e] : 0.f);
+                        DT<T>::st(dst + e, o[e]);
+                    }
+                }
+                if constexpr (EPI == EPI_STORE) {
+                    if (do_stats) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float rv = (float)(T)o[e];  // statistics of the tensor as stored
+                            st[j][e] += rv;
+                            st2[j][e] += rv * rv;
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == EPI_STORE) {
+            if (do_stats) {
+                // sum over the 16 voxel lanes of each lane-quarter, then one LDS atomic per (cout, moment)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = st[j][e], b = st2[j][e];
+#pragma unroll
+                        for (int o2 = 1; o2 < 16; o2 <<= 1) {
+                            a += __shfl_xor(a, o2);
+                            b += __shfl_xor(b, o2);
+                        }
+                        if (r == 0) {
+                            const int cl = j * 16 + q * 4 + e;
+                            atomicAdd(&spart[(n * COUTB + cl) * 2 + 0], a);
+                            atomicAdd(&spart[(n * COUTB + cl) * 2 + 1], b);
+                        }
+                    }
+            }
+        }
+    }
+    if constexpr (EPI == EPI_STORE) {
+        if (do_stats) {
+            __syncthreads();
+            const int PN = p.N * COUTB * 2;
+            float* wsp = p.stats_ws + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * PN;
+            for (int i = tid; i < PN; i += NTHREADS) wsp[i] = spart[i];
+            int* flag = (int*)(spart + C::STAT_FLOATS);
+            if (grid_last_block(p.counter, gridDim.x * gridDim.y, flag)) {
+                // NTHREADS/PARTS outputs at a time, PARTS threads share one output (fixed summation order)
+                constexpr int PARTS = 4;
+                const int nout = gridDim.y * PN;
+                const int sub = tid % PARTS;
+                for (int base = 0; base < nout; base += NTHREADS / PARTS) {
+                    const int o = base + tid / PARTS;
+                    float s = 0.f;
+                    const bool ok = o < nout;
+                    const int y = ok ? o / PN : 0, i = ok ? o % PN : 0;
+                    if (ok) {
+                        const float* src = p.stats_ws + (long long)y * gridDim.x * PN + i;
+#pragma unroll 8
+                        for (int x = sub; x < (int)gridDim.x; x += PARTS) s += src[(long long)x * PN];
+                    }
+                    s += __shfl_xor(s, 1);
+                    s += __shfl_xor(s, 2);
+                    if (ok && sub == 0) {
+                        const int k = i & 1, cl = (i >> 1) % COUTB, nn = i / (2 * COUTB);
+                        const int cg = y * COUTB + cl;
+                        if (cg < p.M) p.stats[((long long)nn * p.M + cg) * 2 + k] = s;
+                    }
                 }
             }
         }
@@ -307,7 +388,8 @@ int msseg_cout_block(int M) {
 }
 
 int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
-                        int N, int D, int H, int W, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+                        int N, int D, int H, int W, int Cin, int Cout, float* stats, void* scratch,
+                        size_t scratch_bytes, int dtype, msseg_stream_t stream) {
     const int esz = dtype == MSSEG_F32 ? 4 : 2;
     int rc = check_common(x, ldx, wp, y, ldy, dtype, esz);
     if (rc) return rc;
@@ -317,6 +399,15 @@ int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const floa
     IgemmParams p{};
     p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy;
     p.N = N; p.D = D; p.H = H; p.W = W; p.K = Cin; p.M = Cout;
+    if (stats) {
+        if (N > MSSEG_STATS_NMAX) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3: fused statistics need N <= %d", MSSEG_STATS_NMAX);
+        if (!scratch || ((uintptr_t)scratch & 255) || scratch_bytes < msseg_reduce_scratch_bytes())
+            MSSEG_FAIL(MSSEG_EWORKSPACE, "conv3d_k3: fused statistics need a zero-initialised scratch of %zu bytes",
+                       msseg_reduce_scratch_bytes());
+        p.stats = stats;
+        p.counter = (unsigned int*)scratch;
+        p.stats_ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+    }
     return dtype == MSSEG_F32 ? launch_k3<float>(p, (hipStream_t)stream) : launch_k3<bf16_t>(p, (hipStream_t)stream);
 }
 

@@ -255,22 +255,38 @@ struct ReduceParams {
     int mblks, kblks, nslots, cbw, accumulate;
 };
 
-__global__ void wgrad_reduce_kernel(const ReduceParams p) {
+// 256 threads = 32 outputs x 8 slot groups: each thread sums every 8th slab, LDS adds the 8 partial sums in a
+// fixed order (deterministic), one thread per output writes the torch-layout gradient.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceParams p) {
+    __shared__ float part[8][33];
     const long long total = (long long)p.M * p.T * p.K;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % p.K);
-        const int t = (int)((i / p.K) % p.T);
-        const int m = (int)(i / ((long long)p.K * p.T));
-        const int mb = m / p.cbw, ml = m % p.cbw, kb = k / p.cbw, kl = k % p.cbw;
-        const long long slabf = (long long)p.T * p.cbw * p.cbw;
-        const float* src = p.slabs + ((long long)(mb * p.kblks + kb) * p.nslots) * slabf +
-                           ((long long)t * p.cbw + ml) * p.cbw + kl;
+    const int ol = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const long long slabf = (long long)p.T * p.cbw * p.cbw;
+    for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
+        const long long i = base + ol;
         float s = 0.f;
-        for (int sl = 0; sl < p.nslots; ++sl) s += src[(long long)sl * slabf];
-        const long long di = (long long)(m / p.M0) * p.s_m1 + (long long)(m % p.M0) * p.s_m0 + (long long)t * p.s_t +
-                             (long long)(k / p.K0) * p.s_k1 + (long long)(k % p.K0) * p.s_k0;
-        p.dw[di] = p.accumulate ? p.dw[di] + s : s;
+        int k = 0, t = 0, m = 0;
+        if (i < total) {
+            k = (int)(i % p.K);
+            t = (int)((i / p.K) % p.T);
+            m = (int)(i / ((long long)p.K * p.T));
+            const int mb = m / p.cbw, ml = m % p.cbw, kb = k / p.cbw, kl = k % p.cbw;
+            const float* src = p.slabs + ((long long)(mb * p.kblks + kb) * p.nslots) * slabf +
+                               ((long long)t * p.cbw + ml) * p.cbw + kl;
+#pragma unroll 4
+            for (int sl = sg; sl < p.nslots; sl += 8) s += src[(long long)sl * slabf];
+        }
+        part[sg][ol] = s;
+        __syncthreads();
+        if (sg == 0 && i < total) {
+            float tot = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) tot += part[g][ol];
+            const long long di = (long long)(m / p.M0) * p.s_m1 + (long long)(m % p.M0) * p.s_m0 + (long long)t * p.s_t +
+                                 (long long)(k / p.K0) * p.s_k1 + (long long)(k % p.K0) * p.s_k0;
+            p.dw[di] = p.accumulate ? p.dw[di] + tot : tot;
+        }
+        __syncthreads();
     }
 }
 
@@ -309,8 +325,8 @@ int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes
     rp.slabs = p.slabs;
     rp.mblks = p.mblks; rp.kblks = p.kblks; rp.nslots = (int)gx * wave_slots; rp.cbw = C::CBW;
     const long long total = (long long)rp.M * rp.T * rp.K;
-    int rb = (int)((total + 255) / 256);
-    if (rb > 2048) rb = 2048;
+    int rb = (int)((total + 31) / 32);
+    if (rb > 4096) rb = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, rp);
     MSSEG_CHECK_LAUNCH("wgrad_reduce");
     return MSSEG_OK;

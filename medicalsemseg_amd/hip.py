@@ -30,7 +30,8 @@ SIGNATURES = {
     "msseg_packed_weight_bytes": ([_i, _i, _i, _i, _i], _sz),
     "msseg_pack_weights": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp], _i),
     "msseg_cout_block": ([_i], _i),
-    "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
+    "msseg_reduce_scratch_bytes": ([], _sz),
     "msseg_conv3d_k1_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_gather_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_deconv_k2s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -40,15 +41,15 @@ SIGNATURES = {
     "msseg_conv3d_k1_wgrad": ([_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_gather_wgrad": ([_vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_deconv_k2s2_wgrad": ([_vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
-    "msseg_channel_stats": ([_vp, _ll, _vp, _i, _ll, _i, _i, _vp], _i),
+    "msseg_channel_stats": ([_vp, _ll, _vp, _i, _ll, _i, _vp, _sz, _i, _vp], _i),
     "msseg_instnorm_act_fwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
-    "msseg_instnorm_act_bwd_reduce": ([_vp, _ll, _vp, _vp, _ll, _vp, _ll, _vp, _i, _ll, _i, _f, _f, _i, _vp], _i),
+    "msseg_instnorm_act_bwd_reduce": ([_vp, _ll, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _ll, _i, _f, _f, _vp, _sz, _i, _vp], _i),
     "msseg_instnorm_act_bwd_apply": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
     "msseg_maxpool2_fwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_maxpool2_bwd": ([_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_ncdhw_to_ndhwc": ([_vp, _i, _vp, _ll, _i, _i, _i, _ll, _vp], _i),
     "msseg_ndhwc_to_ncdhw": ([_vp, _ll, _i, _vp, _i, _i, _i, _ll, _vp], _i),
-    "msseg_channel_sum": ([_vp, _ll, _vp, _ll, _i, _i, _i, _vp], _i),
+    "msseg_channel_sum": ([_vp, _ll, _vp, _ll, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_add": ([_vp, _ll, _vp, _ll, _vp, _ll, _ll, _i, _i, _vp], _i),
     "msseg_dice_ce_partials": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _i, _ll, _i, _vp], _i),
     "msseg_dice_ce_finalize": ([_vp, _vp, _i, _ll, _i, _f, _f, _vp], _i),
@@ -230,15 +231,32 @@ TIMER = KernelTimer()
 # --------------------------------------------------------------------------------------------
 # igemm forward-shaped ops.  x, y: [N, D, H, W, C] channels-last (views allowed)
 # --------------------------------------------------------------------------------------------
-def conv3d_k3(x, wp, bias, y, cin, cout):
+_scratch_cache = {}
+
+
+def scratch(device) -> torch.Tensor:
+    """zero-initialised scratch for the deterministic two-stage reductions (one per device, stable address)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _scratch_cache.get(key)
+    if buf is None:
+        buf = torch.zeros(lib().msseg_reduce_scratch_bytes() + 256, dtype=torch.uint8, device=device)
+        off = (-buf.data_ptr()) % 256
+        buf = buf[off:off + lib().msseg_reduce_scratch_bytes()]
+        _scratch_cache[key] = buf
+    return buf
+
+
+def conv3d_k3(x, wp, bias, y, cin, cout, stats=None):
+    """stats: optional [N, cout, 2] fp32 output = (sum, sum of squares) of y (fused InstanceNorm statistics)."""
     _need_gpu(x, wp, y)
     N, D, H, W = x.shape[:4]
     nv = N * D * H * W
     esz = x.element_size()
+    sc = scratch(x.device) if stats is not None else None
 
     def go():
-        _ck(lib().msseg_conv3d_k3_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, dt(x),
-                                      _stream()), "conv3d_k3_fwd")
+        _ck(lib().msseg_conv3d_k3_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, _p(stats),
+                                      _p(sc), sc.numel() if sc is not None else 0, dt(x), _stream()), "conv3d_k3_fwd")
     TIMER.launch("conv3d_k3_fwd", 2.0 * nv * 27 * cin * cout, nv * (cin + cout) * esz + 27 * cin * cout * esz, go)
     return y
 
@@ -343,8 +361,10 @@ def channel_stats(x, stats=None):
     _need_gpu(x)
     N, S, Cc = _nsc(x)
     if stats is None:
-        stats = torch.zeros(N, Cc, 2, dtype=torch.float32, device=x.device)
-    _ck(lib().msseg_channel_stats(_p(x), ld(x), _p(stats), N, S, Cc, dt(x), _stream()), "channel_stats")
+        stats = torch.empty(N, Cc, 2, dtype=torch.float32, device=x.device)
+    sc = scratch(x.device)
+    _ck(lib().msseg_channel_stats(_p(x), ld(x), _p(stats), N, S, Cc, _p(sc), sc.numel(), dt(x), _stream()),
+        "channel_stats")
     return stats
 
 
@@ -357,13 +377,17 @@ def instnorm_act_fwd(x, stats, gamma, beta, y, slope, eps=1e-5, residual=None):
     return y
 
 
-def instnorm_act_bwd(x, stats, gamma, y, dy, dx, slope, eps=1e-5, dres=None):
-    """returns red[N][C][2] = (sum dz, sum dz*xhat): dbeta = red[...,0].sum(0), dgamma = red[...,1].sum(0)."""
+def instnorm_act_bwd(x, stats, gamma, y, dy, dx, slope, eps=1e-5, dres=None, dgamma=None, dbeta=None,
+                     accumulate=False):
+    """dx (and dres) from dy; the affine gradients dgamma/dbeta (fp32 [C]) are written (or accumulated) by the
+    reduce kernel's finalising block.  Returns red[N][C][2] = (sum dz, sum dz*xhat)."""
     _need_gpu(x, stats, y, dy, dx)
     N, S, Cc = _nsc(x)
-    red = torch.zeros(N, Cc, 2, dtype=torch.float32, device=x.device)
-    _ck(lib().msseg_instnorm_act_bwd_reduce(_p(x), ld(x), _p(stats), _p(y), ld(y), _p(dy), ld(dy), _p(red), N, S, Cc,
-                                            eps, slope, dt(x), _stream()), "instnorm_act_bwd_reduce")
+    red = torch.empty(N, Cc, 2, dtype=torch.float32, device=x.device)
+    sc = scratch(x.device)
+    _ck(lib().msseg_instnorm_act_bwd_reduce(_p(x), ld(x), _p(stats), _p(y), ld(y), _p(dy), ld(dy), _p(red),
+                                            _p(dgamma), _p(dbeta), int(accumulate), N, S, Cc, eps, slope, _p(sc),
+                                            sc.numel(), dt(x), _stream()), "instnorm_act_bwd_reduce")
     _ck(lib().msseg_instnorm_act_bwd_apply(_p(x), ld(x), _p(stats), _p(gamma), _p(y), ld(y), _p(dy), ld(dy), _p(red),
                                            _p(dx), ld(dx), _p(dres), ld(dres) if dres is not None else 0, N, S, Cc, eps,
                                            slope, dt(x), _stream()), "instnorm_act_bwd_apply")
@@ -409,7 +433,9 @@ def channel_sum(x, out, accumulate=False):
     _need_gpu(x, out)
     Cc = x.shape[-1]
     rows = x.numel() // Cc
-    _ck(lib().msseg_channel_sum(_p(x), ld(x), _p(out), rows, Cc, int(accumulate), dt(x), _stream()), "channel_sum")
+    sc = scratch(x.device)
+    _ck(lib().msseg_channel_sum(_p(x), ld(x), _p(out), rows, Cc, int(accumulate), _p(sc), sc.numel(), dt(x),
+                                _stream()), "channel_sum")
     return out
 
 

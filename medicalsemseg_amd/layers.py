@@ -67,18 +67,25 @@ class Conv3:
     def _gather(self, dtype):
         return self.cin % (8 if dtype == torch.bfloat16 else 4) != 0
 
-    def fwd(self, x, out=None):
+    def fwd(self, x, out=None, want_stats=False):
+        """returns y, or (y, stats) when want_stats: InstanceNorm statistics of y, fused into the conv epilogue
+        where the kernel supports it, otherwise one extra pass."""
         dtype = x.dtype
         y = out if out is not None else _empty_like_vol(x, self.cout)
+        stats = None
         if self._gather(dtype):
             wp = self.cache.get(self.w, dtype, "g", lambda: hip.pack_conv_gather(self.w.detach(), dtype))
             hip.conv3d_gather(x, wp, self.b, y, self.cin, self.cout, 3, 1, 1)
         else:
             wp = self.cache.get(self.w, dtype, "f", lambda: hip.pack_conv_k3(self.w.detach(), dtype))
-            hip.conv3d_k3(x, wp, self.b, y, self.cin, self.cout)
+            if want_stats and x.shape[0] <= 8:
+                stats = torch.empty(x.shape[0], self.cout, 2, dtype=torch.float32, device=x.device)
+            hip.conv3d_k3(x, wp, self.b, y, self.cin, self.cout, stats)
+        if want_stats:
+            return y, (stats if stats is not None else hip.channel_stats(y))
         return y
 
-    def bwd(self, x, dy, need_dx=True, dx_out=None):
+    def bwd(self, x, dy, need_dx=True, dx_out=None, bias_grad_is_zero=False):
         dtype = x.dtype
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
@@ -88,7 +95,13 @@ class Conv3:
                 hip.conv3d_k3_wgrad(x, dy, g, self.cin, self.cout, acc)
         if self.b is not None and self.b.requires_grad:
             g, acc = _grad_buf(self.b)
-            hip.channel_sum(dy, g, acc)
+            if bias_grad_is_zero:
+                # a bias feeding InstanceNorm: d loss / d bias == 0 identically (the mean subtraction removes it);
+                # dy sums to zero over every (n, c) by construction of the InstanceNorm backward
+                if not acc:
+                    g.zero_()
+            else:
+                hip.channel_sum(dy, g, acc)
         if not need_dx:
             return None
         if self._gather(dtype):
@@ -172,8 +185,9 @@ class InstNormAct:
                  eps: float = 1e-5):
         self.gamma, self.beta, self.slope, self.eps = gamma, beta, float(slope), float(eps)
 
-    def fwd(self, y_raw, out=None, residual=None):
-        stats = hip.channel_stats(y_raw)
+    def fwd(self, y_raw, out=None, residual=None, stats=None):
+        if stats is None:
+            stats = hip.channel_stats(y_raw)
         a = out if out is not None else torch.empty_like(y_raw, memory_format=torch.contiguous_format)
         hip.instnorm_act_fwd(y_raw, stats, self.gamma, self.beta, a, self.slope, self.eps, residual)
         return a, stats
@@ -181,13 +195,13 @@ class InstNormAct:
     def bwd(self, y_raw, stats, a, da, want_dres=False):
         dy = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device)
         dres = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device) if want_dres else None
-        red = hip.instnorm_act_bwd(y_raw, stats, self.gamma, a, da, dy, self.slope, self.eps, dres)
+        dg = db = None
+        acc = False
         if self.gamma is not None and self.gamma.requires_grad:
-            g = red[..., 1].sum(0)
-            self.gamma.grad = g if self.gamma.grad is None else self.gamma.grad + g
-        if self.beta is not None and self.beta.requires_grad:
-            g = red[..., 0].sum(0)
-            self.beta.grad = g if self.beta.grad is None else self.beta.grad + g
+            dg, acc = _grad_buf(self.gamma)
+            db, acc2 = _grad_buf(self.beta)
+            assert acc == acc2
+        hip.instnorm_act_bwd(y_raw, stats, self.gamma, a, da, dy, self.slope, self.eps, dres, dg, db, acc)
         return (dy, dres) if want_dres else dy
 
 
@@ -198,14 +212,14 @@ class ConvNormAct:
         self.conv, self.norm = conv, norm
 
     def fwd(self, x, out=None):
-        y = self.conv.fwd(x)
-        a, stats = self.norm.fwd(y, out)
+        y, stats = self.conv.fwd(x, want_stats=True)
+        a, stats = self.norm.fwd(y, out, stats=stats)
         return a, (x, y, stats, a)
 
     def bwd(self, saved, da, need_dx=True):
         x, y, stats, a = saved
         dy = self.norm.bwd(y, stats, a, da)
-        return self.conv.bwd(x, dy, need_dx)
+        return self.conv.bwd(x, dy, need_dx, bias_grad_is_zero=True)
 
 
 def maxpool_fwd(x):
