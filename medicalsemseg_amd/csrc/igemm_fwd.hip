@@ -59,7 +59,7 @@ struct IgemmCfg {
     static constexpr int A_BYTES = ((4 * PLANE + 64 + 255) / 256) * 256;
     static constexpr int B_BYTES = NTAPS * 4 * COUTB * 16;
     static constexpr int STAT_FLOATS = MSSEG_STATS_NMAX * COUTB * 2;
-    static constexpr int STAT_BYTES = (EPI == EPI_STORE) ? STAT_FLOATS * 4 + 256 : 0;
+    static constexpr int STAT_BYTES = (EPI == EPI_STORE) ? (STAT_FLOATS + WAVES * COUTB * 2) * 4 + 256 : 0;
     static constexpr int LDS_BYTES = A_BYTES + B_BYTES + STAT_BYTES;
     static_assert(TV % (16 * WAVES) == 0, "tile must split into 16-voxel MFMA tiles per wave");
 };
@@ -92,201 +92,261 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
         abase[m] = aoff(q, PLANE) + ((td * PH + th) * PW + tw) * 16;
     }
     const int bbase = (q * COUTB + r) * 16;
-    int kb_loaded = -1;
     float* spart = (float*)(smem + C::A_BYTES + C::B_BYTES);
     const bool do_stats = (EPI == EPI_STORE) && p.stats != nullptr;
+    float* wpart = spart + C::STAT_FLOATS;  // [WAVES][COUTB][2] staging for the per-sample flush
     if (do_stats) {
         for (int i = tid; i < C::STAT_FLOATS; i += NTHREADS) spart[i] = 0.f;
     }
-
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        int t = tile;
-        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
-        const int th_i = t % p.tiles_h; t /= p.tiles_h;
-        const int td_i = t % p.tiles_d; t /= p.tiles_d;
-        const int n = t;
-        const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
-
-        f32x4_t acc[MT][NT];
+    float st[NT][4], st2[NT][4];  // this lane's running (sum, sum of squares) of the current sample
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-        for (int kb = 0; kb < p.NKB; ++kb) {
-            __syncthreads();
-            // ---------------- stage A ----------------
-            for (int i = tid; i < HV * 4; i += NTHREADS) {
-                const int cq = i & 3, hv = i >> 2;
-                const int c = kb * CB + cq * EPC;
-                u32x4_t val = {0u, 0u, 0u, 0u};
-                if constexpr (SRC == SRC_DIRECT) {
-                    const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
-                    const int d = d0 - PAD + hd, h = h0 - PAD + hh, w = w0 - PAD + hw;
-                    if (c < p.K && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H &&
-                        (unsigned)w < (unsigned)p.W) {
-                        const long long vox = (((long long)n * p.D + d) * p.H + h) * p.W + w;
-                        val = *(const u32x4_t*)(xg + vox * p.ldx + c);
-                    }
-                } else if constexpr (SRC == SRC_GATHER) {
-                    const int ov = w0 + hv;  // flat output voxel
-                    if (ov < p.W && c < p.K) {
-                        int tt = ov;
-                        const int ow = tt % p.OW; tt /= p.OW;
-                        const int oh = tt % p.OH; tt /= p.OH;
-                        const int od = tt % p.OD; const int nn = tt / p.OD;
-                        alignas(16) T tmp[EPC];
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) {
-                            const int vc = c + e;
-                            float fv = 0.f;
-                            if (vc < p.K) {
-                                const int tap = vc / p.cin, ci = vc - tap * p.cin;
-                                const int kw = tap % p.k, kh = (tap / p.k) % p.k, kd = tap / (p.k * p.k);
-                                const int id = od * p.s - p.p + kd, ih = oh * p.s - p.p + kh, iw = ow * p.s - p.p + kw;
-                                if ((unsigned)id < (unsigned)p.ID && (unsigned)ih < (unsigned)p.IH &&
-                                    (unsigned)iw < (unsigned)p.IW) {
-                                    const long long vox = (((long long)nn * p.ID + id) * p.IH + ih) * p.IW + iw;
-                                    fv = DT<T>::ld(xg + vox * p.ldx + ci);
-                                }
-                            }
-                            DT<T>::st(&tmp[e], fv);
-                        }
-                        val = *(const u32x4_t*)tmp;
-                    }
-                } else {  // SRC_DECONV_BWD: coarse voxel gathers its 8 fine children
-                    const int cv = w0 + hv;
-                    if (cv < p.W && c < p.K) {
-                        int tt = cv;
-                        const int cw = tt % p.OW; tt /= p.OW;
-                        const int ch = tt % p.OH; tt /= p.OH;
-                        const int cd = tt % p.OD; const int nn = tt / p.OD;
-                        const int abc = c / p.creal, co = c - abc * p.creal;
-                        const int fd = 2 * cd + (abc >> 2), fh = 2 * ch + ((abc >> 1) & 1), fw = 2 * cw + (abc & 1);
-                        const long long vox = (((long long)nn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
-                        val = *(const u32x4_t*)(xg + vox * p.ldx + co);
-                    }
-                }
-                *(u32x4_t*)(ldsA + aoff(cq, PLANE) + hv * 16) = val;
-            }
-            // ---------------- stage B (skipped while the resident block is the one needed) ----------------
-            if (kb_loaded != kb) {
-                const u32x4_t* src = (const u32x4_t*)((const unsigned char*)p.wp +
-                                                      ((long long)coutblk * p.NKB + kb) * C::B_BYTES);
-                for (int i = tid; i < C::B_BYTES / 16; i += NTHREADS) ((u32x4_t*)ldsB)[i] = src[i];
-                kb_loaded = kb;
-            }
-            __syncthreads();
-            // ---------------- MFMA ----------------
-#pragma unroll
-            for (int tap = 0; tap < NTAPS; ++tap) {
-                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                const int toff = (NTAPS == 27) ? ((kd * PH + kh) * PW + kw) * 16 : 0;
-                u32x4_t bf[NT];
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    bf[j] = *(const u32x4_t*)(ldsB + bbase + tap * (4 * COUTB * 16) + j * 256);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const u32x4_t af = *(const u32x4_t*)(ldsA + abase[m] + toff);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) mma_chunk<T>(acc[m][j], bf[j], af);
-                }
-            }
-        }
-        // ---------------- epilogue ----------------
-        float st[NT][4], st2[NT][4];
+        for (int e = 0; e < 4; ++e) st[j][e] = st2[j][e] = 0.f;
+    int cur_n = -1;
+    // Flush = fixed-order reduction lanes -> wave -> workgroup, so the statistics are bit-reproducible.
+    auto flush_stats = [&](int nn) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) st[j][e] = st2[j][e] = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                float a = st[j][e], b = st2[j][e];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int v = (wave * MT + m) * 16 + r;
-            const int td = v / (TH * TW), th = (v / TW) % TH, tw = v % TW;
-            const int d = d0 + td, h = h0 + th, w = w0 + tw;
-            if (d >= p.D || h >= p.H || w >= p.W) continue;
-            long long vox;
-            int dn = 0, dd = 0, dh = 0, dw = 0;
+                for (int o2 = 1; o2 < 16; o2 <<= 1) {
+                    a += __shfl_xor(a, o2);
+                    b += __shfl_xor(b, o2);
+                }
+                if (r == 0) {
+                    const int cl = j * 16 + q * 4 + e;
+                    wpart[(wave * COUTB + cl) * 2 + 0] = a;
+                    wpart[(wave * COUTB + cl) * 2 + 1] = b;
+                }
+                st[j][e] = st2[j][e] = 0.f;
+            }
+        __syncthreads();
+        if (tid < COUTB * 2) {
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < WAVES; ++wv) s += wpart[wv * COUTB * 2 + tid];
+            spart[nn * COUTB * 2 + tid] += s;
+        }
+        __syncthreads();
+    };
+
+    // ---------------------------------------------------------------------------------------------
+    // Software pipeline over stages (tile, channel block): the global loads of stage s+1 are issued right
+    // after stage s's LDS image is complete and stay in flight under stage s's MFMAs; they are written to
+    // LDS after the barrier that ends stage s (issue-early / write-late register staging).
+    // ---------------------------------------------------------------------------------------------
+    constexpr int NIT_A = (HV * 4 + NTHREADS - 1) / NTHREADS;
+    constexpr int NIT_B = (C::B_BYTES / 16 + NTHREADS - 1) / NTHREADS;
+    struct TileCo { int n, d0, h0, w0; };
+    auto decode = [&](int tile) {
+        TileCo tc;
+        int t = tile;
+        tc.w0 = (t % p.tiles_w) * TW; t /= p.tiles_w;
+        tc.h0 = (t % p.tiles_h) * TH; t /= p.tiles_h;
+        tc.d0 = (t % p.tiles_d) * TD; t /= p.tiles_d;
+        tc.n = t;
+        return tc;
+    };
+    auto load_a_chunk = [&](const TileCo& tc, int kb, int i) -> u32x4_t {
+        const int cq = i & 3, hv = i >> 2;
+        const int c = kb * CB + cq * EPC;
+        u32x4_t val = {0u, 0u, 0u, 0u};
+        if constexpr (SRC == SRC_DIRECT) {
+            const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
+            const int d = tc.d0 - PAD + hd, h = tc.h0 - PAD + hh, w = tc.w0 - PAD + hw;
+            if (c < p.K && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
+                const long long vox = (((long long)tc.n * p.D + d) * p.H + h) * p.W + w;
+                val = *(const u32x4_t*)(xg + vox * p.ldx + c);
+            }
+        } else if constexpr (SRC == SRC_GATHER) {
+            const int ov = tc.w0 + hv;  // flat output voxel
+            if (ov < p.W && c < p.K) {
+                int tt = ov;
+                const int ow = tt % p.OW; tt /= p.OW;
+                const int oh = tt % p.OH; tt /= p.OH;
+                const int od = tt % p.OD; const int nn = tt / p.OD;
+                alignas(16) T tmp[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const int vc = c + e;
+                    float fv = 0.f;
+                    if (vc < p.K) {
+                        const int tap = vc / p.cin, ci = vc - tap * p.cin;
+                        const int kw = tap % p.k, kh = (tap / p.k) % p.k, kd = tap / (p.k * p.k);
+                        const int id = od * p.s - p.p + kd, ih = oh * p.s - p.p + kh, iw = ow * p.s - p.p + kw;
+                        if ((unsigned)id < (unsigned)p.ID && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
+                            const long long vox = (((long long)nn * p.ID + id) * p.IH + ih) * p.IW + iw;
+                            fv = DT<T>::ld(xg + vox * p.ldx + ci);
+                        }
+                    }
+                    DT<T>::st(&tmp[e], fv);
+                }
+                val = *(const u32x4_t*)tmp;
+            }
+        } else {  // SRC_DECONV_BWD: coarse voxel gathers its 8 fine children
+            const int cv = tc.w0 + hv;
+            if (cv < p.W && c < p.K) {
+                int tt = cv;
+                const int cw = tt % p.OW; tt /= p.OW;
+                const int ch = tt % p.OH; tt /= p.OH;
+                const int cd = tt % p.OD; const int nn = tt / p.OD;
+                const int abc = c / p.creal, co = c - abc * p.creal;
+                const int fd = 2 * cd + (abc >> 2), fh = 2 * ch + ((abc >> 1) & 1), fw = 2 * cw + (abc & 1);
+                const long long vox = (((long long)nn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
+                val = *(const u32x4_t*)(xg + vox * p.ldx + co);
+            }
+        }
+        return val;
+    };
+    u32x4_t pa[NIT_A], pb[NIT_B];
+    auto fetch = [&](const TileCo& tc, int kb, bool with_b) {
+#pragma unroll
+        for (int it = 0; it < NIT_A; ++it) {
+            const int i = tid + it * NTHREADS;
+            pa[it] = (i < HV * 4) ? load_a_chunk(tc, kb, i) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+        if (with_b) {
+            const u32x4_t* src = (const u32x4_t*)((const unsigned char*)p.wp + ((long long)coutblk * p.NKB + kb) * C::B_BYTES);
+#pragma unroll
+            for (int it = 0; it < NIT_B; ++it) {
+                const int i = tid + it * NTHREADS;
+                pb[it] = (i < C::B_BYTES / 16) ? src[i] : u32x4_t{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    auto commit = [&](bool with_b) {
+#pragma unroll
+        for (int it = 0; it < NIT_A; ++it) {
+            const int i = tid + it * NTHREADS;
+            if (i < HV * 4) *(u32x4_t*)(ldsA + aoff(i & 3, PLANE) + (i >> 2) * 16) = pa[it];
+        }
+        if (with_b) {
+#pragma unroll
+            for (int it = 0; it < NIT_B; ++it) {
+                const int i = tid + it * NTHREADS;
+                if (i < C::B_BYTES / 16) ((u32x4_t*)ldsB)[i] = pb[it];
+            }
+        }
+    };
+
+    f32x4_t acc[MT][NT];
+    int tile = blockIdx.x, kb = 0;
+    TileCo tc = decode(tile < p.ntiles ? tile : 0);
+    bool b_pending = true;
+    if (tile < p.ntiles) fetch(tc, 0, true);
+    while (tile < p.ntiles) {
+        __syncthreads();  // everyone finished reading the previous stage's LDS image
+        commit(b_pending);
+        __syncthreads();
+        int ntile = tile, nkb = kb + 1;
+        if (nkb == p.NKB) { nkb = 0; ntile = tile + gridDim.x; }
+        const TileCo ntc = decode(ntile < p.ntiles ? ntile : 0);
+        b_pending = p.NKB > 1;
+        if (ntile < p.ntiles) fetch(ntc, nkb, b_pending);
+
+        const int n = tc.n, d0 = tc.d0, h0 = tc.h0, w0 = tc.w0;
+        if (kb == 0) {
             if constexpr (EPI == EPI_STORE) {
-                vox = (((long long)n * p.D + d) * p.H + h) * p.W + w;
-            } else {
-                int tt = w;
-                dw = tt % p.OW; tt /= p.OW;
-                dh = tt % p.OH; tt /= p.OH;
-                dd = tt % p.OD; dn = tt / p.OD;
-                vox = 0;
+                if (do_stats && n != cur_n) {
+                    if (cur_n >= 0) flush_stats(cur_n);
+                    cur_n = n;
+                }
             }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int co = coutblk * COUTB + j * 16 + q * 4;
-                if (co >= p.M) continue;
-                f32x4_t o = acc[m][j];
-                T* dst;
-                int cbase;
-                if constexpr (EPI == EPI_STORE) {
-                    cbase = co;
-                    dst = yg + vox * p.ldy + co;
-                } else {
-                    const int abc = co / p.creal;
-                    cbase = co - abc * p.creal;
-                    const int fd = 2 * dd + (abc >> 2), fh = 2 * dh + ((abc >> 1) & 1), fw = 2 * dw + (abc & 1);
-                    const long long fv = (((long long)dn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
-                    dst = yg + fv * p.ldy + cbase;
-                }
-                if (p.vec_store && co + 4 <= p.M) {
-                    if (p.bias) {
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += p.bias[cbase + e];
-                    }
-                    store4<T>(dst, o);
-                } else {
-                    for (int e = 0; e < 4 && co + e < p.M; ++e) {
-                        o[e] += (p.bias ? p.bias[cbase + e] : 0.f);
-                        DT<T>::st(dst + e, o[e]);
-                    }
-                }
-                if constexpr (EPI == EPI_STORE) {
-                    if (do_stats) {
+                for (int j = 0; j < NT; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---------------- MFMA ----------------
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float rv = (float)(T)o[e];  // statistics of the tensor as stored
-                            st[j][e] += rv;
-                            st2[j][e] += rv * rv;
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int toff = (NTAPS == 27) ? ((kd * PH + kh) * PW + kw) * 16 : 0;
+            u32x4_t bf[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bf[j] = *(const u32x4_t*)(ldsB + bbase + tap * (4 * COUTB * 16) + j * 256);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const u32x4_t af = *(const u32x4_t*)(ldsA + abase[m] + toff);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) mma_chunk<T>(acc[m][j], bf[j], af);
+            }
+        }
+        if (kb == p.NKB - 1) {
+            // ---------------- epilogue ----------------
+    #pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int v = (wave * MT + m) * 16 + r;
+                const int td = v / (TH * TW), th = (v / TW) % TH, tw = v % TW;
+                const int d = d0 + td, h = h0 + th, w = w0 + tw;
+                if (d >= p.D || h >= p.H || w >= p.W) continue;
+                long long vox;
+                int dn = 0, dd = 0, dh = 0, dw = 0;
+                if constexpr (EPI == EPI_STORE) {
+                    vox = (((long long)n * p.D + d) * p.H + h) * p.W + w;
+                } else {
+                    int tt = w;
+                    dw = tt % p.OW; tt /= p.OW;
+                    dh = tt % p.OH; tt /= p.OH;
+                    dd = tt % p.OD; dn = tt / p.OD;
+                    vox = 0;
+                }
+    #pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int co = coutblk * COUTB + j * 16 + q * 4;
+                    if (co >= p.M) continue;
+                    f32x4_t o = acc[m][j];
+                    T* dst;
+                    int cbase;
+                    if constexpr (EPI == EPI_STORE) {
+                        cbase = co;
+                        dst = yg + vox * p.ldy + co;
+                    } else {
+                        const int abc = co / p.creal;
+                        cbase = co - abc * p.creal;
+                        const int fd = 2 * dd + (abc >> 2), fh = 2 * dh + ((abc >> 1) & 1), fw = 2 * dw + (abc & 1);
+                        const long long fv = (((long long)dn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
+                        dst = yg + fv * p.ldy + cbase;
+                    }
+                    if (p.vec_store && co + 4 <= p.M) {
+                        if (p.bias) {
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += p.bias[cbase + e];
+                        }
+                        store4<T>(dst, o);
+                    } else {
+                        for (int e = 0; e < 4 && co + e < p.M; ++e) {
+                            o[e] += (p.bias ? p.bias[cbase + e] : 0.f);
+                            DT<T>::st(dst + e, o[e]);
+                        }
+                    }
+                    if constexpr (EPI == EPI_STORE) {
+                        if (do_stats) {
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float rv = (float)(T)o[e];  // statistics of the tensor as stored
+                                st[j][e] += rv;
+                                st2[j][e] += rv * rv;
+                            }
                         }
                     }
                 }
             }
         }
-        if constexpr (EPI == EPI_STORE) {
-            if (do_stats) {
-                // sum over the 16 voxel lanes of each lane-quarter, then one LDS atomic per (cout, moment)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float a = st[j][e], b = st2[j][e];
-#pragma unroll
-                        for (int o2 = 1; o2 < 16; o2 <<= 1) {
-                            a += __shfl_xor(a, o2);
-                            b += __shfl_xor(b, o2);
-                        }
-                        if (r == 0) {
-                            const int cl = j * 16 + q * 4 + e;
-                            atomicAdd(&spart[(n * COUTB + cl) * 2 + 0], a);
-                            atomicAdd(&spart[(n * COUTB + cl) * 2 + 1], b);
-                        }
-                    }
-            }
-        }
+        tile = ntile; kb = nkb; tc = ntc;
     }
     if constexpr (EPI == EPI_STORE) {
         if (do_stats) {
+            if (cur_n >= 0) flush_stats(cur_n);
             __syncthreads();
             const int PN = p.N * COUTB * 2;
             float* wsp = p.stats_ws + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * PN;
             for (int i = tid; i < PN; i += NTHREADS) wsp[i] = spart[i];
-            int* flag = (int*)(spart + C::STAT_FLOATS);
+            int* flag = (int*)(wpart + WAVES * COUTB * 2);
             if (grid_last_block(p.counter, gridDim.x * gridDim.y, flag)) {
                 // NTHREADS/PARTS outputs at a time, PARTS threads share one output (fixed summation order)
                 constexpr int PARTS = 4;

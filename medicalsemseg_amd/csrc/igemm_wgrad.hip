@@ -81,88 +81,121 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int b = 0; b < CT; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    // software pipeline: the next tile's P/Q chunks are loaded into registers while this tile's MFMAs run
+    constexpr int NIT_P = (TV * 4 + 255) / 256, NIT_Q = (HV * 4 + 255) / 256;
+    struct TileCo { int n, d0, h0, w0; };
+    auto decode = [&](int tile) {
+        TileCo tc;
         int t = tile;
-        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
-        const int th_i = t % p.tiles_h; t /= p.tiles_h;
-        const int td_i = t % p.tiles_d; t /= p.tiles_d;
-        const int n = t;
-        const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
-        __syncthreads();
-        // ---- stage P: TV rows x CBW channels ----
-        for (int i = tid; i < TV * 4; i += 256) {
-            const int cq = i & 3, tv = i >> 2;
-            const int c = mblk * CBW + cq * EPC;
-            const int td = tv / (TH * TW), th = (tv / TW) % TH, tw = tv % TW;
-            const int d = d0 + td, h = h0 + th, w = w0 + tw;
-            u32x4_t val = {0u, 0u, 0u, 0u};
-            if (d < p.D && h < p.H && w < p.W && c < p.M) {
-                const long long vox = (((long long)n * p.D + d) * p.H + h) * p.W + w;
-                const T* src = pg + vox * p.ldp + c;
-                if (c + EPC <= p.M) {
-                    val = *(const u32x4_t*)src;
-                } else {
-                    alignas(16) T tmp[EPC];
+        tc.w0 = (t % p.tiles_w) * TW; t /= p.tiles_w;
+        tc.h0 = (t % p.tiles_h) * TH; t /= p.tiles_h;
+        tc.d0 = (t % p.tiles_d) * TD; t /= p.tiles_d;
+        tc.n = t;
+        return tc;
+    };
+    auto load_p = [&](const TileCo& tc, int i) -> u32x4_t {
+        const int cq = i & 3, tv = i >> 2;
+        const int c = mblk * CBW + cq * EPC;
+        const int td = tv / (TH * TW), th = (tv / TW) % TH, tw = tv % TW;
+        const int d = tc.d0 + td, h = tc.h0 + th, w = tc.w0 + tw;
+        u32x4_t val = {0u, 0u, 0u, 0u};
+        if (d < p.D && h < p.H && w < p.W && c < p.M) {
+            const long long vox = (((long long)tc.n * p.D + d) * p.H + h) * p.W + w;
+            const T* src = pg + vox * p.ldp + c;
+            if (c + EPC <= p.M) {
+                val = *(const u32x4_t*)src;
+            } else {
+                alignas(16) T tmp[EPC];
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) DT<T>::st(&tmp[e], (c + e < p.M) ? DT<T>::ld(src + e) : 0.f);
-                    val = *(const u32x4_t*)tmp;
-                }
+                for (int e = 0; e < EPC; ++e) DT<T>::st(&tmp[e], (c + e < p.M) ? DT<T>::ld(src + e) : 0.f);
+                val = *(const u32x4_t*)tmp;
             }
-            *(u32x4_t*)(ldsP + tv * RS + cq * 16) = val;
         }
-        // ---- stage Q: HV rows x CBW channels ----
-        for (int i = tid; i < HV * 4; i += 256) {
-            const int cq = i & 3, hv = i >> 2;
-            const int c = kblk * CBW + cq * EPC;
-            u32x4_t val = {0u, 0u, 0u, 0u};
-            if constexpr (QSRC == Q_DIRECT) {
-                const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
-                const int d = d0 - PAD + hd, h = h0 - PAD + hh, w = w0 - PAD + hw;
-                if (c < p.K && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
-                    const long long vox = (((long long)n * p.D + d) * p.H + h) * p.W + w;
-                    val = *(const u32x4_t*)(qg + vox * p.ldq + c);
-                }
-            } else if constexpr (QSRC == Q_GATHER) {
-                const int ov = w0 + hv;
-                if (ov < p.W && c < p.K) {
-                    int tt = ov;
-                    const int ow = tt % p.OW; tt /= p.OW;
-                    const int oh = tt % p.OH; tt /= p.OH;
-                    const int od = tt % p.OD; const int nn = tt / p.OD;
-                    alignas(16) T tmp[EPC];
+        return val;
+    };
+    auto load_q = [&](const TileCo& tc, int i) -> u32x4_t {
+        const int cq = i & 3, hv = i >> 2;
+        const int c = kblk * CBW + cq * EPC;
+        u32x4_t val = {0u, 0u, 0u, 0u};
+        if constexpr (QSRC == Q_DIRECT) {
+            const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
+            const int d = tc.d0 - PAD + hd, h = tc.h0 - PAD + hh, w = tc.w0 - PAD + hw;
+            if (c < p.K && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
+                const long long vox = (((long long)tc.n * p.D + d) * p.H + h) * p.W + w;
+                val = *(const u32x4_t*)(qg + vox * p.ldq + c);
+            }
+        } else if constexpr (QSRC == Q_GATHER) {
+            const int ov = tc.w0 + hv;
+            if (ov < p.W && c < p.K) {
+                int tt = ov;
+                const int ow = tt % p.OW; tt /= p.OW;
+                const int oh = tt % p.OH; tt /= p.OH;
+                const int od = tt % p.OD; const int nn = tt / p.OD;
+                alignas(16) T tmp[EPC];
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        const int vc = c + e;
-                        float fv = 0.f;
-                        if (vc < p.K) {
-                            const int tap = vc / p.cin, ci = vc - tap * p.cin;
-                            const int kw = tap % p.k, kh = (tap / p.k) % p.k, kd = tap / (p.k * p.k);
-                            const int id = od * p.s - p.p + kd, ih = oh * p.s - p.p + kh, iw = ow * p.s - p.p + kw;
-                            if ((unsigned)id < (unsigned)p.ID && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
-                                const long long vox = (((long long)nn * p.ID + id) * p.IH + ih) * p.IW + iw;
-                                fv = DT<T>::ld(qg + vox * p.ldq + ci);
-                            }
+                for (int e = 0; e < EPC; ++e) {
+                    const int vc = c + e;
+                    float fv = 0.f;
+                    if (vc < p.K) {
+                        const int tap = vc / p.cin, ci = vc - tap * p.cin;
+                        const int kw = tap % p.k, kh = (tap / p.k) % p.k, kd = tap / (p.k * p.k);
+                        const int id = od * p.s - p.p + kd, ih = oh * p.s - p.p + kh, iw = ow * p.s - p.p + kw;
+                        if ((unsigned)id < (unsigned)p.ID && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
+                            const long long vox = (((long long)nn * p.ID + id) * p.IH + ih) * p.IW + iw;
+                            fv = DT<T>::ld(qg + vox * p.ldq + ci);
                         }
-                        DT<T>::st(&tmp[e], fv);
                     }
-                    val = *(const u32x4_t*)tmp;
+                    DT<T>::st(&tmp[e], fv);
                 }
-            } else {  // Q_DECONV: virtual channel (abc, co) of coarse voxel = fine child abc, channel co
-                const int cv = w0 + hv;
-                if (cv < p.W && c < p.K) {
-                    int tt = cv;
-                    const int cw = tt % p.OW; tt /= p.OW;
-                    const int ch = tt % p.OH; tt /= p.OH;
-                    const int cd = tt % p.OD; const int nn = tt / p.OD;
-                    const int abc = c / p.creal, co = c - abc * p.creal;
-                    const int fd = 2 * cd + (abc >> 2), fh = 2 * ch + ((abc >> 1) & 1), fw = 2 * cw + (abc & 1);
-                    const long long vox = (((long long)nn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
-                    val = *(const u32x4_t*)(qg + vox * p.ldq + co);
-                }
+                val = *(const u32x4_t*)tmp;
             }
-            *(u32x4_t*)(ldsQ + hv * RS + cq * 16) = val;
+        } else {  // Q_DECONV: virtual channel (abc, co) of coarse voxel = fine child abc, channel co
+            const int cv = tc.w0 + hv;
+            if (cv < p.W && c < p.K) {
+                int tt = cv;
+                const int cw = tt % p.OW; tt /= p.OW;
+                const int ch = tt % p.OH; tt /= p.OH;
+                const int cd = tt % p.OD; const int nn = tt / p.OD;
+                const int abc = c / p.creal, co = c - abc * p.creal;
+                const int fd = 2 * cd + (abc >> 2), fh = 2 * ch + ((abc >> 1) & 1), fw = 2 * cw + (abc & 1);
+                const long long vox = (((long long)nn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
+                val = *(const u32x4_t*)(qg + vox * p.ldq + co);
+            }
         }
+        return val;
+    };
+    u32x4_t pp[NIT_P], pq[NIT_Q];
+    auto fetch = [&](const TileCo& tc) {
+#pragma unroll
+        for (int it = 0; it < NIT_P; ++it) {
+            const int i = tid + it * 256;
+            pp[it] = (i < TV * 4) ? load_p(tc, i) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int it = 0; it < NIT_Q; ++it) {
+            const int i = tid + it * 256;
+            pq[it] = (i < HV * 4) ? load_q(tc, i) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT_P; ++it) {
+            const int i = tid + it * 256;
+            if (i < TV * 4) *(u32x4_t*)(ldsP + (i >> 2) * RS + (i & 3) * 16) = pp[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT_Q; ++it) {
+            const int i = tid + it * 256;
+            if (i < HV * 4) *(u32x4_t*)(ldsQ + (i >> 2) * RS + (i & 3) * 16) = pq[it];
+        }
+    };
+
+    if ((int)blockIdx.x < p.ntiles) fetch(decode(blockIdx.x));
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         __syncthreads();
+        commit();
+        __syncthreads();
+        if (tile + (int)gridDim.x < p.ntiles) fetch(decode(tile + gridDim.x));
         // ---- MFMA over the tile's voxels ----
         const int ks_begin = (NTAPS == 27) ? 0 : wave;
         const int ks_step = (NTAPS == 27) ? 1 : C::WAVES;
