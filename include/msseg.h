@@ -66,6 +66,12 @@ int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const floa
                         int N, int D, int H, int W, int Cin, int Cout, float* stats /* nullable: fused InstanceNorm
                         statistics stats[n][cout][2] = (sum, sum of squares) of y as stored; needs N <= 8 */,
                         void* scratch, size_t scratch_bytes, int dtype, msseg_stream_t stream);
+/* Conv3d k=3 s=2 p=1 (PatchMerging.reduction, models/backbones/swin_nnformer.py:297): x [N,ID,IH,IW,Cin] ->
+ * y [N,(ID-1)/2+1,...,Cout].  Its input / weight gradients run as stride-1 problems on msseg_zero_stuff2(dy). */
+int msseg_conv3d_k3s2_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                          int N, int ID, int IH, int IW, int Cin, int Cout, int dtype, msseg_stream_t stream);
+int msseg_zero_stuff2(const void* dy, long long lddy, void* out, long long ldo, int N, int OD, int OH, int OW, int ID,
+                      int IH, int IW, int C, int dtype, msseg_stream_t stream);
 /* Conv3d k=1 (UnetResBlock.conv3, UnetOutBlock models/segmentors/swin_unetr.py:130, BasicUNet final_conv). */
 int msseg_conv3d_k1_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                         long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
@@ -143,6 +149,32 @@ int msseg_channel_sum(const void* x, long long ldx, float* out, long long rows, 
 /* y = a + b (elementwise over rows x C with strides) */
 int msseg_add(const void* a, long long lda, const void* b, long long ldb, void* y, long long ldy, long long rows,
               int C, int dtype, msseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Swin transformer pieces (models/backbones/swin_nnformer.py).  Linear layers are msseg_conv3d_k1_* on tokens.
+ * ------------------------------------------------------------------------------------------- */
+/* Shifted-window attention between the qkv and proj Linears (swin_nnformer.py:128-196 inside :235-289):
+ * qkv [B,S,H,W,3C] (channel = which*C + head*hd + e) -> out [B,S,H,W,C].  Window partition, cyclic shift, zero
+ * padding to a window multiple (padded tokens carry qkv_bias), the relative-position bias table
+ * [(2ws-1)^3][heads] and the -100 region mask are all applied through addressing; lse [B*nW][heads][ws^3] is
+ * saved for the backward.  head_dim in {8,16,32}. */
+int msseg_window_attention_fwd(const void* qkv, const float* qkv_bias, const float* table, void* out, float* lse, int B,
+                               int S, int H, int W, int C, int heads, int ws, int shift, int dtype,
+                               msseg_stream_t stream);
+/* dqkv fully written for every token; dtable (nullable) ACCUMULATED (caller zero-fills when needed). */
+int msseg_window_attention_bwd(const void* qkv, const float* qkv_bias, const float* table, const void* out,
+                               const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
+                               int C, int heads, int ws, int shift, int dtype, msseg_stream_t stream);
+/* LayerNorm over the channel dim of rows x C (nn.LayerNorm, eps 1e-5); mean/rstd [rows] saved for backward. */
+int msseg_layernorm_fwd(const void* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
+                        float* mean, float* rstd, long long rows, int C, float eps, int dtype, msseg_stream_t stream);
+/* dgamma/dbeta (nullable, both or none) are ACCUMULATED. */
+int msseg_layernorm_bwd(const void* x, long long ldx, const float* gamma, const float* mean, const float* rstd,
+                        const void* dy, long long lddy, void* dx, long long lddx, float* dgamma, float* dbeta,
+                        long long rows, int C, int dtype, msseg_stream_t stream);
+/* exact (erf) GELU */
+int msseg_gelu_fwd(const void* x, void* y, long long n, int dtype, msseg_stream_t stream);
+int msseg_gelu_bwd(const void* x, const void* dy, void* dx, long long n, int dtype, msseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dice + cross-entropy loss (MONAI DiceCELoss(to_onehot_y, softmax, squared_pred) as built at

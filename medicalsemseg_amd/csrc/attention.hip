@@ -1,0 +1,489 @@
+// Swin 3-D shifted-window attention (forward + backward), LayerNorm over channels, GELU.
+//
+// Window attention replaces swin_nnformer.py:235-289 + :128-196 of the reference between the qkv Linear and the
+// proj Linear:  pad -> roll(-shift) -> window_partition -> softmax(q k^T * scale + bias[+mask]) v -> window_reverse
+// -> roll(+shift) -> crop.  Nothing is materialised: the kernel addresses tokens of the [B,S,H,W,3C] qkv tensor
+// through the (shift, window, position) map, synthesises padded tokens (qkv = qkv bias), derives the -100 region
+// mask from coordinates, and streams keys through LDS with an online softmax, so the [B_,h,N,N] score tensor
+// never exists.  This is the exact-fp32-math version used for both dtypes (bf16 I/O, fp32 accumulate); one
+// workgroup = one window, one thread = one query (forward / dQ) or one key (dK, dV).
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+    const void* qkv;      // [B, S, H, W, 3C]  channel = which*C + head*hd + e
+    const float* qkv_bias;  // [3C] or null (value of padded tokens)
+    const float* table;   // relative position bias table [(2ws-1)^3][heads]
+    void* out;            // [B, S, H, W, C]
+    float* lse;           // [B, nW, heads, N]   log-sum-exp per query (saved for backward)
+    const void* dout;     // backward: [B,S,H,W,C]
+    void* dqkv;           // backward: [B,S,H,W,3C]
+    float* dtable;        // backward: [(2ws-1)^3][heads] fp32, accumulated (atomics from per-workgroup LDS sums)
+    int dtab_all_heads;   // the workgroup keeps dtable partial sums for all heads in LDS across its windows
+    int B, S, H, W, C, heads, hd, ws, shift;
+    int Sp, Hp, Wp, nWs, nWh, nWw, N, M3, nwin_total;
+    float scale;
+    int use_mask;
+};
+
+MSSEG_DEVFN int region_id(int z, int Lp, int ws, int shift) { return z < Lp - ws ? 0 : (z < Lp - shift ? 1 : 2); }
+
+// token of window (wz,wy,wx) position p: returns linear voxel index in [0, S*H*W) or -1 for a padded token;
+// reg = region id triple packed (only meaningful when shift > 0)
+MSSEG_DEVFN int window_token(const AttnParams& p, int wz, int wy, int wx, int pos, int& reg, int& code) {
+    const int ws = p.ws;
+    const int pz = pos / (ws * ws), py = (pos / ws) % ws, px = pos % ws;
+    code = (pz * (2 * ws - 1) + py) * (2 * ws - 1) + px;  // rel_index(i, j) = code_i - code_j + off
+    const int sz = wz * ws + pz, sy = wy * ws + py, sx = wx * ws + px;  // coordinates in the shifted, padded grid
+    reg = region_id(sz, p.Sp, ws, p.shift) * 9 + region_id(sy, p.Hp, ws, p.shift) * 3 + region_id(sx, p.Wp, ws, p.shift);
+    int z = sz + p.shift, y = sy + p.shift, x = sx + p.shift;      // shifted[i] = x[(i + shift) mod Lp]
+    if (z >= p.Sp) z -= p.Sp;
+    if (y >= p.Hp) y -= p.Hp;
+    if (x >= p.Wp) x -= p.Wp;
+    if (z >= p.S || y >= p.H || x >= p.W) return -1;
+    return (z * p.H + y) * p.W + x;
+}
+
+constexpr int HD_MAX = 32;
+
+// ---------------------------------------------------------------------------------------------------------
+// forward: grid (nW, B), block 256.  Loops heads; per head K,V of the window live in LDS (fp32).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void win_attn_fwd_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* kS = (float*)smem;            // [N][HD]
+    float* vS = kS + p.N * HD;           // [N][HD]
+    float* tabS = vS + p.N * HD;         // [M3] bias table of the current head
+    int* tok = (int*)(tabS + p.M3);      // [N] voxel index or -1
+    int* regS = tok + p.N;               // [N]
+    int* codeS = regS + p.N;             // [N]
+    const int nW = p.nWs * p.nWh * p.nWw;
+    const int m = 2 * p.ws - 1;
+    const int off = ((p.ws - 1) * m + (p.ws - 1)) * m + (p.ws - 1);
+    for (int wb = blockIdx.x; wb < p.nwin_total; wb += gridDim.x) {
+        const int w = wb % nW, b = wb / nW;
+        const int wx = w % p.nWw, wy = (w / p.nWw) % p.nWh, wz = w / (p.nWw * p.nWh);
+        const T* qkv = (const T*)p.qkv + (long long)b * p.S * p.H * p.W * 3 * p.C;
+        T* out = (T*)p.out + (long long)b * p.S * p.H * p.W * p.C;
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.N; i += 256) {
+            int rg, cd;
+            tok[i] = window_token(p, wz, wy, wx, i, rg, cd);
+            regS[i] = rg;
+            codeS[i] = cd;
+        }
+        for (int h = 0; h < p.heads; ++h) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < p.M3; i += 256) tabS[i] = p.table[(long long)i * p.heads + h];
+            for (int i = threadIdx.x; i < p.N * HD; i += 256) {
+                const int j = i / HD, e = i % HD;
+                const int t = tok[j];
+                const int ck = p.C + h * HD + e, cv = 2 * p.C + h * HD + e;
+                float kv, vv;
+                if (t >= 0) {
+                    kv = DT<T>::ld(qkv + (long long)t * 3 * p.C + ck);
+                    vv = DT<T>::ld(qkv + (long long)t * 3 * p.C + cv);
+                } else {
+                    kv = p.qkv_bias ? p.qkv_bias[ck] : 0.f;
+                    vv = p.qkv_bias ? p.qkv_bias[cv] : 0.f;
+                    if (sizeof(T) == 2) { kv = (float)(bf16_t)kv; vv = (float)(bf16_t)vv; }
+                }
+                kS[i] = kv;
+                vS[i] = vv;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < p.N; i += 256) {
+                const int t = tok[i];
+                float q[HD], o[HD];
+#pragma unroll
+                for (int e = 0; e < HD; ++e) {
+                    float qv;
+                    if (t >= 0) qv = DT<T>::ld(qkv + (long long)t * 3 * p.C + h * HD + e);
+                    else {
+                        qv = p.qkv_bias ? p.qkv_bias[h * HD + e] : 0.f;
+                        if (sizeof(T) == 2) qv = (float)(bf16_t)qv;
+                    }
+                    q[e] = qv * p.scale;
+                    o[e] = 0.f;
+                }
+                const int ri = regS[i], ci = codeS[i] + off;
+                float mx = -INFINITY, l = 0.f;
+                for (int j = 0; j < p.N; ++j) {
+                    float sc = 0.f;
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) sc += q[e] * kS[j * HD + e];
+                    sc += tabS[ci - codeS[j]];
+                    if (p.use_mask && regS[j] != ri) sc += -100.f;
+                    const float mn = fmaxf(mx, sc);
+                    const float a = expf(mx - mn), pe = expf(sc - mn);
+                    l = l * a + pe;
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) o[e] = o[e] * a + pe * vS[j * HD + e];
+                    mx = mn;
+                }
+                const float inv = 1.f / l;
+                p.lse[((long long)wb * p.heads + h) * p.N + i] = mx + logf(l);
+                if (t >= 0) {
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) DT<T>::st(out + (long long)t * p.C + h * HD + e, o[e] * inv);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward: grid (nW, B), block 256.  Per head: Q, K, V, dO rows, lse, delta in LDS; phase A thread = query
+// (dQ, dbias), phase B thread = key (dK, dV).  Gradients of padded tokens are dropped (they are constants).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void win_attn_bwd_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qS = (float*)smem;          // [N][HD]  (already scaled)
+    float* kS = qS + p.N * HD;
+    float* vS = kS + p.N * HD;
+    float* dS = vS + p.N * HD;         // dO [N][HD]
+    float* lseS = dS + p.N * HD;       // [N]
+    float* delS = lseS + p.N;          // [N]  delta_i = dO_i . O_i
+    float* tabS = delS + p.N;          // [M3]
+    int* tok = (int*)(tabS + p.M3);
+    int* regS = tok + p.N;
+    int* codeS = regS + p.N;
+    float* dtabS = (float*)(codeS + p.N);  // [M3] or [heads][M3]
+    const int nW = p.nWs * p.nWh * p.nWw;
+    const int m = 2 * p.ws - 1;
+    const int off = ((p.ws - 1) * m + (p.ws - 1)) * m + (p.ws - 1);
+    const long long vol = (long long)p.S * p.H * p.W;
+    const int ndt = p.dtable ? (p.dtab_all_heads ? p.heads * p.M3 : p.M3) : 0;
+    for (int i = threadIdx.x; i < ndt; i += 256) dtabS[i] = 0.f;
+    for (int wb = blockIdx.x; wb < p.nwin_total; wb += gridDim.x) {
+        const int w = wb % nW, b = wb / nW;
+        const int wx = w % p.nWw, wy = (w / p.nWw) % p.nWh, wz = w / (p.nWw * p.nWh);
+        const T* qkv = (const T*)p.qkv + b * vol * 3 * p.C;
+        const T* outp = (const T*)p.out + b * vol * p.C;
+        const T* dout = (const T*)p.dout + b * vol * p.C;
+        T* dqkv = (T*)p.dqkv + b * vol * 3 * p.C;
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.N; i += 256) {
+            int rg, cd;
+            tok[i] = window_token(p, wz, wy, wx, i, rg, cd);
+            regS[i] = rg;
+            codeS[i] = cd;
+        }
+        for (int h = 0; h < p.heads; ++h) {
+            __syncthreads();
+            float* dtab = p.dtab_all_heads ? dtabS + h * p.M3 : dtabS;
+            for (int i = threadIdx.x; i < p.M3; i += 256) tabS[i] = p.table[(long long)i * p.heads + h];
+            for (int i = threadIdx.x; i < p.N * HD; i += 256) {
+                const int j = i / HD, e = i % HD;
+                const int t = tok[j];
+                const int c = h * HD + e;
+                float qv, kv, vv, dov = 0.f;
+                if (t >= 0) {
+                    const T* row = qkv + (long long)t * 3 * p.C;
+                    qv = DT<T>::ld(row + c); kv = DT<T>::ld(row + p.C + c); vv = DT<T>::ld(row + 2 * p.C + c);
+                    dov = DT<T>::ld(dout + (long long)t * p.C + c);
+                } else {
+                    qv = p.qkv_bias ? p.qkv_bias[c] : 0.f;
+                    kv = p.qkv_bias ? p.qkv_bias[p.C + c] : 0.f;
+                    vv = p.qkv_bias ? p.qkv_bias[2 * p.C + c] : 0.f;
+                    if (sizeof(T) == 2) { qv = (float)(bf16_t)qv; kv = (float)(bf16_t)kv; vv = (float)(bf16_t)vv; }
+                }
+                qS[i] = qv * p.scale; kS[i] = kv; vS[i] = vv; dS[i] = dov;
+            }
+            for (int i = threadIdx.x; i < p.N; i += 256) {
+                lseS[i] = p.lse[((long long)wb * p.heads + h) * p.N + i];
+                const int t = tok[i];
+                float d = 0.f;
+                if (t >= 0) {
+#pragma unroll
+                    for (int e = 0; e < HD; ++e)
+                        d += DT<T>::ld(dout + (long long)t * p.C + h * HD + e) * DT<T>::ld(outp + (long long)t * p.C + h * HD + e);
+                }
+                delS[i] = d;
+            }
+            __syncthreads();
+            // phase A: thread = query i -> dQ_i ; dtable[rel(i,j)] += dS_ij
+            for (int i = threadIdx.x; i < p.N; i += 256) {
+                float q[HD], dq[HD], dO[HD];
+#pragma unroll
+                for (int e = 0; e < HD; ++e) { q[e] = qS[i * HD + e]; dO[e] = dS[i * HD + e]; dq[e] = 0.f; }
+                const float lse = lseS[i], del = delS[i];
+                const int ri = regS[i], ci = codeS[i] + off;
+                const bool live = tok[i] >= 0;
+                for (int j = 0; j < p.N; ++j) {
+                    float sc = 0.f, dp = 0.f;
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) { sc += q[e] * kS[j * HD + e]; dp += dO[e] * vS[j * HD + e]; }
+                    const int ti = ci - codeS[j];
+                    sc += tabS[ti];
+                    if (p.use_mask && regS[j] != ri) sc += -100.f;
+                    const float pr = expf(sc - lse);
+                    const float ds = pr * (dp - del);
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) dq[e] += ds * kS[j * HD + e];
+                    if (p.dtable && live) atomicAdd(&dtab[ti], ds);
+                }
+                const int t = tok[i];
+                if (t >= 0) {
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) DT<T>::st(dqkv + (long long)t * 3 * p.C + h * HD + e, dq[e] * p.scale);
+                }
+            }
+            // phase B: thread = key j -> dK_j, dV_j
+            for (int j = threadIdx.x; j < p.N; j += 256) {
+                float k[HD], v[HD], dk[HD], dv[HD];
+#pragma unroll
+                for (int e = 0; e < HD; ++e) { k[e] = kS[j * HD + e]; v[e] = vS[j * HD + e]; dk[e] = dv[e] = 0.f; }
+                const int rj = regS[j], cj = off - codeS[j];
+                for (int i = 0; i < p.N; ++i) {
+                    if (tok[i] < 0) continue;  // padded queries produce no output, hence no gradient
+                    float sc = 0.f, dp = 0.f;
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) { sc += qS[i * HD + e] * k[e]; dp += dS[i * HD + e] * v[e]; }
+                    sc += tabS[codeS[i] + cj];
+                    if (p.use_mask && regS[i] != rj) sc += -100.f;
+                    const float pr = expf(sc - lseS[i]);
+                    const float ds = pr * (dp - delS[i]);
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) { dv[e] += pr * dS[i * HD + e]; dk[e] += ds * qS[i * HD + e]; }
+                }
+                const int t = tok[j];
+                if (t >= 0) {
+                    T* row = dqkv + (long long)t * 3 * p.C;
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) {
+                        DT<T>::st(row + p.C + h * HD + e, dk[e]);   // qS already carries the scale
+                        DT<T>::st(row + 2 * p.C + h * HD + e, dv[e]);
+                    }
+                }
+            }
+            if (p.dtable && !p.dtab_all_heads) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < p.M3; i += 256) {
+                    const float v = dtabS[i];
+                    if (v != 0.f) atomicAdd(&p.dtable[(long long)i * p.heads + h], v);
+                    dtabS[i] = 0.f;
+                }
+            }
+        }
+    }
+    if (p.dtable && p.dtab_all_heads) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.heads * p.M3; i += 256) {
+            const float v = dtabS[i];
+            const int h = i / p.M3, e = i % p.M3;
+            if (v != 0.f) atomicAdd(&p.dtable[(long long)e * p.heads + h], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm over channels (one thread per token) and GELU
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, long long ldx, const float* g,
+                                                            const float* bta, T* __restrict__ y, long long ldy,
+                                                            float* mean, float* rstd, long long rows, int C, float eps) {
+    for (long long r = blockIdx.x * 256LL + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+        const T* xr = x + r * ldx;
+        float s = 0.f, s2 = 0.f;
+        for (int c = 0; c < C; ++c) { const float v = DT<T>::ld(xr + c); s += v; s2 += v * v; }
+        const float mu = s / C;
+        float var = s2 / C - mu * mu;
+        var = var > 0.f ? var : 0.f;
+        const float rs = rsqrtf(var + eps);
+        if (mean) { mean[r] = mu; rstd[r] = rs; }
+        T* yr = y + r * ldy;
+        for (int c = 0; c < C; ++c)
+            DT<T>::st(yr + c, (DT<T>::ld(xr + c) - mu) * rs * (g ? g[c] : 1.f) + (bta ? bta[c] : 0.f));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, long long ldx, const float* g,
+                                                            const float* mean, const float* rstd,
+                                                            const T* __restrict__ dy, long long lddy, T* __restrict__ dx,
+                                                            long long lddx, float* dg, float* db, long long rows, int C) {
+    extern __shared__ float acc[];  // [2][C] block partials
+    for (int c = threadIdx.x; c < 2 * C; c += 256) acc[c] = 0.f;
+    __syncthreads();
+    for (long long r = blockIdx.x * 256LL + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+        const T* xr = x + r * ldx;
+        const T* dr = dy + r * lddy;
+        const float mu = mean[r], rs = rstd[r];
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float dyg = DT<T>::ld(dr + c) * (g ? g[c] : 1.f);
+            const float xh = (DT<T>::ld(xr + c) - mu) * rs;
+            a += dyg; b += dyg * xh;
+        }
+        a /= C; b /= C;
+        T* dxr = dx + r * lddx;
+        for (int c = 0; c < C; ++c) {
+            const float d = DT<T>::ld(dr + c);
+            const float xh = (DT<T>::ld(xr + c) - mu) * rs;
+            DT<T>::st(dxr + c, rs * (d * (g ? g[c] : 1.f) - a - xh * b));
+            if (dg) { atomicAdd(&acc[c], d * xh); atomicAdd(&acc[C + c], d); }
+        }
+    }
+    __syncthreads();
+    if (dg)
+        for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(&dg[c], acc[c]); atomicAdd(&db[c], acc[C + c]); }
+}
+
+template <typename T, bool BWD>
+__global__ void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, long long n) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = DT<T>::ld(x + i);
+        const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+        if constexpr (!BWD) DT<T>::st(out + i, v * cdf);
+        else DT<T>::st(out + i, DT<T>::ld(dy + i) * (cdf + v * 0.3989422804014327f * expf(-0.5f * v * v)));
+    }
+}
+
+inline int grid_for(long long total, int per_thread = 4) {
+    long long b = ceil_div_ll(total, 256LL * per_thread);
+    const long long cap = (long long)msseg_num_cus() * 16;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int fill_attn(AttnParams& p, int B, int S, int H, int W, int C, int heads, int ws, int shift) {
+    if (B < 1 || S < 1 || H < 1 || W < 1 || heads < 1 || C % heads || ws < 1 || shift < 0 || shift >= ws)
+        MSSEG_FAIL(MSSEG_EINVAL, "window_attention: bad shape");
+    p.B = B; p.S = S; p.H = H; p.W = W; p.C = C; p.heads = heads; p.hd = C / heads; p.ws = ws; p.shift = shift;
+    p.nWs = ceil_div(S, ws); p.nWh = ceil_div(H, ws); p.nWw = ceil_div(W, ws);
+    p.Sp = p.nWs * ws; p.Hp = p.nWh * ws; p.Wp = p.nWw * ws;
+    p.N = ws * ws * ws;
+    p.M3 = (2 * ws - 1) * (2 * ws - 1) * (2 * ws - 1);
+    p.nwin_total = p.nWs * p.nWh * p.nWw * B;
+    p.scale = 1.0f / sqrtf((float)p.hd);
+    p.use_mask = shift > 0;
+    if (p.hd != 8 && p.hd != 16 && p.hd != 32) MSSEG_FAIL(MSSEG_EINVAL, "window_attention: head_dim %d not in {8,16,32}", p.hd);
+    if (p.N > 512) MSSEG_FAIL(MSSEG_EINVAL, "window_attention: window of %d tokens too large", p.N);
+    return MSSEG_OK;
+}
+
+#define ATTN_LAUNCH(KERN, T_, SMEM)                                                                      \
+    do {                                                                                                 \
+        int gx__ = p.nwin_total < msseg_num_cus() * 2 ? p.nwin_total : msseg_num_cus() * 2;              \
+        dim3 grid(gx__, 1);                                                                              \
+        if (p.hd == 8) { if (int rc__ = attn_set_lds((const void*)KERN<T_, 8>, SMEM)) return rc__;          \
+            hipLaunchKernelGGL((KERN<T_, 8>), grid, dim3(256), SMEM, (hipStream_t)stream, p); }              \
+        else if (p.hd == 16) { if (int rc__ = attn_set_lds((const void*)KERN<T_, 16>, SMEM)) return rc__;   \
+            hipLaunchKernelGGL((KERN<T_, 16>), grid, dim3(256), SMEM, (hipStream_t)stream, p); }             \
+        else { if (int rc__ = attn_set_lds((const void*)KERN<T_, 32>, SMEM)) return rc__;                   \
+            hipLaunchKernelGGL((KERN<T_, 32>), grid, dim3(256), SMEM, (hipStream_t)stream, p); }             \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+static int attn_set_lds(const void* kern, size_t smem) {
+    if (smem > 64 * 1024 &&
+        hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        MSSEG_FAIL(MSSEG_ELAUNCH, "window_attention: cannot set %zu bytes of dynamic LDS", smem);
+    return MSSEG_OK;
+}
+
+int msseg_window_attention_fwd(const void* qkv, const float* qkv_bias, const float* table, void* out, float* lse, int B,
+                               int S, int H, int W, int C, int heads, int ws, int shift, int dtype,
+                               msseg_stream_t stream) {
+    if (!qkv || !table || !out || !lse) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd: null pointer");
+    AttnParams p{};
+    if (int rc = fill_attn(p, B, S, H, W, C, heads, ws, shift)) return rc;
+    p.qkv = qkv; p.qkv_bias = qkv_bias; p.table = table; p.out = out; p.lse = lse;
+    const size_t smem = (size_t)p.N * p.hd * 2 * 4 + (size_t)p.M3 * 4 + (size_t)p.N * 3 * 4;
+    if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd: window too large for LDS");
+    if (dtype == MSSEG_F32) ATTN_LAUNCH(win_attn_fwd_kernel, float, smem);
+    else if (dtype == MSSEG_BF16) ATTN_LAUNCH(win_attn_fwd_kernel, bf16_t, smem);
+    else MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd: bad dtype");
+    MSSEG_CHECK_LAUNCH("window_attention_fwd");
+    return MSSEG_OK;
+}
+
+int msseg_window_attention_bwd(const void* qkv, const float* qkv_bias, const float* table, const void* out,
+                               const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
+                               int C, int heads, int ws, int shift, int dtype, msseg_stream_t stream) {
+    if (!qkv || !table || !out || !lse || !dout || !dqkv) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd: null pointer");
+    AttnParams p{};
+    if (int rc = fill_attn(p, B, S, H, W, C, heads, ws, shift)) return rc;
+    p.qkv = qkv; p.qkv_bias = qkv_bias; p.table = table; p.out = (void*)out; p.lse = (float*)lse; p.dout = dout;
+    p.dqkv = dqkv; p.dtable = dtable;
+    const size_t base = (size_t)p.N * p.hd * 4 * 4 + (size_t)p.N * 5 * 4 + (size_t)p.M3 * 4;
+    p.dtab_all_heads = (base + (size_t)heads * p.M3 * 4 <= 96 * 1024) ? 1 : 0;
+    const size_t smem = base + (size_t)(p.dtab_all_heads ? heads : 1) * p.M3 * 4;
+    if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd: window too large for LDS (%zu bytes)", smem);
+    if (dtype == MSSEG_F32) ATTN_LAUNCH(win_attn_bwd_kernel, float, smem);
+    else if (dtype == MSSEG_BF16) ATTN_LAUNCH(win_attn_bwd_kernel, bf16_t, smem);
+    else MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd: bad dtype");
+    MSSEG_CHECK_LAUNCH("window_attention_bwd");
+    return MSSEG_OK;
+}
+
+int msseg_layernorm_fwd(const void* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
+                        float* mean, float* rstd, long long rows, int C, float eps, int dtype, msseg_stream_t stream) {
+    if (!x || !y || rows < 1 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "layernorm_fwd: bad args");
+    const int g = grid_for(rows, 1);
+    if (dtype == MSSEG_F32)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx,
+                           gamma, beta, (float*)y, ldy, mean, rstd, rows, C, eps);
+    else if (dtype == MSSEG_BF16)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                           gamma, beta, (bf16_t*)y, ldy, mean, rstd, rows, C, eps);
+    else MSSEG_FAIL(MSSEG_EINVAL, "layernorm_fwd: bad dtype");
+    MSSEG_CHECK_LAUNCH("layernorm_fwd");
+    return MSSEG_OK;
+}
+
+int msseg_layernorm_bwd(const void* x, long long ldx, const float* gamma, const float* mean, const float* rstd,
+                        const void* dy, long long lddy, void* dx, long long lddx, float* dgamma, float* dbeta,
+                        long long rows, int C, int dtype, msseg_stream_t stream) {
+    if (!x || !mean || !rstd || !dy || !dx || rows < 1 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "layernorm_bwd: bad args");
+    if ((dgamma == nullptr) != (dbeta == nullptr)) MSSEG_FAIL(MSSEG_EINVAL, "layernorm_bwd: dgamma/dbeta go together");
+    int g = grid_for(rows, 4);
+    if (g > msseg_num_cus() * 2) g = msseg_num_cus() * 2;
+    const size_t smem = (size_t)2 * C * 4;
+    if (dtype == MSSEG_F32)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(g), dim3(256), smem, (hipStream_t)stream, (const float*)x, ldx,
+                           gamma, mean, rstd, (const float*)dy, lddy, (float*)dx, lddx, dgamma, dbeta, rows, C);
+    else if (dtype == MSSEG_BF16)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(g), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)x,
+                           ldx, gamma, mean, rstd, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, dgamma, dbeta, rows, C);
+    else MSSEG_FAIL(MSSEG_EINVAL, "layernorm_bwd: bad dtype");
+    MSSEG_CHECK_LAUNCH("layernorm_bwd");
+    return MSSEG_OK;
+}
+
+int msseg_gelu_fwd(const void* x, void* y, long long n, int dtype, msseg_stream_t stream) {
+    if (!x || !y || n < 1) MSSEG_FAIL(MSSEG_EINVAL, "gelu_fwd: bad args");
+    if (dtype == MSSEG_F32)
+        hipLaunchKernelGGL((gelu_kernel<float, false>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (const float*)nullptr, (float*)y, n);
+    else if (dtype == MSSEG_BF16)
+        hipLaunchKernelGGL((gelu_kernel<bf16_t, false>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, n);
+    else MSSEG_FAIL(MSSEG_EINVAL, "gelu_fwd: bad dtype");
+    MSSEG_CHECK_LAUNCH("gelu_fwd");
+    return MSSEG_OK;
+}
+
+int msseg_gelu_bwd(const void* x, const void* dy, void* dx, long long n, int dtype, msseg_stream_t stream) {
+    if (!x || !dy || !dx || n < 1) MSSEG_FAIL(MSSEG_EINVAL, "gelu_bwd: bad args");
+    if (dtype == MSSEG_F32)
+        hipLaunchKernelGGL((gelu_kernel<float, true>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (const float*)dy, (float*)dx, n);
+    else if (dtype == MSSEG_BF16)
+        hipLaunchKernelGGL((gelu_kernel<bf16_t, true>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n);
+    else MSSEG_FAIL(MSSEG_EINVAL, "gelu_bwd: bad dtype");
+    MSSEG_CHECK_LAUNCH("gelu_bwd");
+    return MSSEG_OK;
+}
+
+}  // extern "C"

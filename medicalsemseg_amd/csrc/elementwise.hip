@@ -90,27 +90,35 @@ inline RowMap row_map(int C, int width) {
 // 1: out[c] (+)= sum_{n,b} (channel sums); 2: red[n][c][k] = sum_b and dparam_k[c] (+)= sum_n red[n][c][k].
 MSSEG_DEVFN void finalize_channels(const float* ws, int N, int nblk, int C, int nper, int mode, float* out,
                                    float* dp0, float* dp1, int accumulate) {
-    constexpr int PARTS = 4;
-    const int sub = threadIdx.x % PARTS;
-    const int nout = C * nper;
-    const long long blk = (long long)C * nper;
-    for (int base = 0; base < nout; base += 256 / PARTS) {
-        const int o = base + threadIdx.x / PARTS;
-        const bool ok = o < nout;
+    // partial matrix: rows (n, b), L = C*nper floats per row.  Threads tile [row group][column]; every thread keeps
+    // UNR loads in flight; row groups are then added in a fixed order through LDS (bit-reproducible).
+    __shared__ float fin[256];
+    const int L = C * nper;
+    const int cols = L < 256 ? L : 256;
+    const int G = 256 / cols;               // row groups
+    const int col = threadIdx.x % cols, rg = threadIdx.x / cols;
+    for (int c0 = 0; c0 < L; c0 += cols) {
+        const int o = c0 + col;
+        const bool ok = o < L && rg < G;
         float tot = 0.f;
         for (int n = 0; n < N; ++n) {
             float s = 0.f;
             if (ok) {
-                const float* src = ws + (long long)n * nblk * blk + o;
-#pragma unroll 8
-                for (int bb = sub; bb < nblk; bb += PARTS) s += src[(long long)bb * blk];
+                const float* src = ws + (long long)n * nblk * L + o;
+#pragma unroll 16
+                for (int bb = rg; bb < nblk; bb += G) s += src[(long long)bb * L];
             }
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            if (ok && sub == 0 && mode != 1) out[(long long)n * blk + o] = s;
-            tot += s;
+            __syncthreads();
+            fin[threadIdx.x] = s;
+            __syncthreads();
+            if (ok && rg == 0) {
+                float t = 0.f;
+                for (int g = 0; g < G; ++g) t += fin[g * cols + col];
+                if (mode != 1) out[(long long)n * L + o] = t;
+                tot += t;
+            }
         }
-        if (ok && sub == 0) {
+        if (ok && rg == 0) {
             if (mode == 1) {
                 out[o] = accumulate ? out[o] + tot : tot;
             } else if (mode == 2) {
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < W; ++e) s[e] = s2[e] = 0.f;
         if (rl < rows_par) {
-#pragma unroll 4
+#pragma unroll 8
             for (long long r = r0 + rl; r < r1; r += rows_par) {
                 if constexpr (VEC) {
                     Chunk<T> c;
@@ -181,8 +189,10 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
 }
 
 inline long long reduce_blocks(long long S, int rows_par, int N, int C, int nper) {
+    // one block per CU in total (each keeps ~32 KB of loads in flight) keeps the finalising block's job small
     long long blocks = ceil_div_ll(S, (long long)rows_par * 8);
-    long long cap = (long long)msseg_num_cus() * 8 / (N > 0 ? N : 1) + 1;
+    long long cap = (long long)msseg_num_cus() / (N > 0 ? N : 1);
+    if (cap < 1) cap = 1;
     const long long fit = (long long)(((size_t)16 << 20) / ((size_t)N * C * nper * 4));
     if (cap > fit) cap = fit;
     if (blocks > cap) blocks = cap;
@@ -502,6 +512,26 @@ __global__ void ndhwc_to_ncdhw_kernel(const TS* __restrict__ src, long long lds,
     }
 }
 
+// out[n][2o] = dy[n][o], zero elsewhere: turns the input gradient / weight gradient of a stride-2 convolution
+// into stride-1 problems on the input grid.
+template <typename T>
+__global__ void zero_stuff2_kernel(const T* __restrict__ dy, long long lddy, T* __restrict__ out, long long ldo, int N,
+                                   int OD, int OH, int OW, int ID, int IH, int IW, int C) {
+    const long long total = (long long)N * ID * IH * IW * C;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int w = (int)(t % IW); t /= IW;
+        const int h = (int)(t % IH); t /= IH;
+        const int d = (int)(t % ID);
+        const int n = (int)(t / ID);
+        float v = 0.f;
+        if (!(d & 1) && !(h & 1) && !(w & 1) && d / 2 < OD && h / 2 < OH && w / 2 < OW)
+            v = DT<T>::ld(dy + ((((long long)n * OD + d / 2) * OH + h / 2) * OW + w / 2) * lddy + c);
+        DT<T>::st(out + ((((long long)n * ID + d) * IH + h) * IW + w) * ldo + c, v);
+    }
+}
+
 template <typename T>
 __global__ void add_kernel(const T* a, long long lda, const T* b, long long ldb, T* y, long long ldy, long long rows,
                            int C) {
@@ -743,6 +773,19 @@ int msseg_ndhwc_to_ncdhw(const void* src, long long lds, int src_dtype, void* ds
         hipLaunchKernelGGL((ndhwc_to_ncdhw_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)src, lds, (bf16_t*)dst, N, C, S);
     else MSSEG_FAIL(MSSEG_EINVAL, "ndhwc_to_ncdhw: bad dtypes");
     MSSEG_CHECK_LAUNCH("ndhwc_to_ncdhw");
+    return MSSEG_OK;
+}
+
+int msseg_zero_stuff2(const void* dy, long long lddy, void* out, long long ldo, int N, int OD, int OH, int OW, int ID,
+                      int IH, int IW, int C, int dtype, msseg_stream_t stream) {
+    if (!dy || !out || N < 1 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "zero_stuff2: bad args");
+    const int g = grid_for((long long)N * ID * IH * IW * C);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(zero_stuff2_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+                                  lddy, (float*)out, ldo, N, OD, OH, OW, ID, IH, IW, C),
+               hipLaunchKernelGGL(zero_stuff2_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream,
+                                  (const bf16_t*)dy, lddy, (bf16_t*)out, ldo, N, OD, OH, OW, ID, IH, IW, C));
+    MSSEG_CHECK_LAUNCH("zero_stuff2");
     return MSSEG_OK;
 }
 

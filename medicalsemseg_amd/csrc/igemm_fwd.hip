@@ -44,12 +44,14 @@ struct IgemmParams {
     unsigned int* counter;
 };
 
-template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT>
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1>
 struct IgemmCfg {
     static constexpr int EPC = DT<T>::EPC;
     static constexpr int CB = 4 * EPC;
     static constexpr int PAD = (NTAPS == 27) ? 1 : 0;
-    static constexpr int PD = TD + 2 * PAD, PH = TH + 2 * PAD, PW = TW + 2 * PAD;
+    // input halo of an output tile: (T-1)*STRIDE + kernel extent
+    static constexpr int PD = (TD - 1) * STRIDE + 1 + 2 * PAD, PH = (TH - 1) * STRIDE + 1 + 2 * PAD,
+                         PW = (TW - 1) * STRIDE + 1 + 2 * PAD;
     static constexpr int HV = PD * PH * PW;
     static constexpr int TV = TD * TH * TW;
     static constexpr int MT = TV / 16 / WAVES;
@@ -66,9 +68,9 @@ struct IgemmCfg {
 
 MSSEG_DEVFN int aoff(int q, int plane) { return q * plane + (q >> 1) * 32; }
 
-template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT>
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1>
 __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams p) {
-    using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT>;
+    using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE>;
     constexpr int EPC = C::EPC, CB = C::CB, PAD = C::PAD, PH = C::PH, PW = C::PW, HV = C::HV, MT = C::MT;
     constexpr int NTHREADS = C::NTHREADS, COUTB = C::COUTB, PLANE = C::PLANE;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
     for (int m = 0; m < MT; ++m) {
         const int v = (wave * MT + m) * 16 + r;
         const int td = v / (TH * TW), th = (v / TW) % TH, tw = v % TW;
-        abase[m] = aoff(q, PLANE) + ((td * PH + th) * PW + tw) * 16;
+        abase[m] = aoff(q, PLANE) + ((td * STRIDE * PH + th * STRIDE) * PW + tw * STRIDE) * 16;
     }
     const int bbase = (q * COUTB + r) * 16;
     float* spart = (float*)(smem + C::A_BYTES + C::B_BYTES);
@@ -156,9 +158,10 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
         u32x4_t val = {0u, 0u, 0u, 0u};
         if constexpr (SRC == SRC_DIRECT) {
             const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
-            const int d = tc.d0 - PAD + hd, h = tc.h0 - PAD + hh, w = tc.w0 - PAD + hw;
-            if (c < p.K && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
-                const long long vox = (((long long)tc.n * p.D + d) * p.H + h) * p.W + w;
+            const int d = tc.d0 * STRIDE - PAD + hd, h = tc.h0 * STRIDE - PAD + hh, w = tc.w0 * STRIDE - PAD + hw;
+            const int XD = STRIDE == 1 ? p.D : p.ID, XH = STRIDE == 1 ? p.H : p.IH, XW = STRIDE == 1 ? p.W : p.IW;
+            if (c < p.K && (unsigned)d < (unsigned)XD && (unsigned)h < (unsigned)XH && (unsigned)w < (unsigned)XW) {
+                const long long vox = (((long long)tc.n * XD + d) * XH + h) * XW + w;
                 val = *(const u32x4_t*)(xg + vox * p.ldx + c);
             }
         } else if constexpr (SRC == SRC_GATHER) {
@@ -348,8 +351,8 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
             for (int i = tid; i < PN; i += NTHREADS) wsp[i] = spart[i];
             int* flag = (int*)(wpart + WAVES * COUTB * 2);
             if (grid_last_block(p.counter, gridDim.x * gridDim.y, flag)) {
-                // NTHREADS/PARTS outputs at a time, PARTS threads share one output (fixed summation order)
-                constexpr int PARTS = 4;
+                // 16 lanes share one output, every lane keeps up to 16 loads in flight; fixed summation order
+                constexpr int PARTS = 16;
                 const int nout = gridDim.y * PN;
                 const int sub = tid % PARTS;
                 for (int base = 0; base < nout; base += NTHREADS / PARTS) {
@@ -359,11 +362,13 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
                     const int y = ok ? o / PN : 0, i = ok ? o % PN : 0;
                     if (ok) {
                         const float* src = p.stats_ws + (long long)y * gridDim.x * PN + i;
-#pragma unroll 8
+#pragma unroll 16
                         for (int x = sub; x < (int)gridDim.x; x += PARTS) s += src[(long long)x * PN];
                     }
                     s += __shfl_xor(s, 1);
                     s += __shfl_xor(s, 2);
+                    s += __shfl_xor(s, 4);
+                    s += __shfl_xor(s, 8);
                     if (ok && sub == 0) {
                         const int k = i & 1, cl = (i >> 1) % COUTB, nn = i / (2 * COUTB);
                         const int cg = y * COUTB + cl;
@@ -375,9 +380,9 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
     }
 }
 
-template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT>
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1>
 int launch_cfg(IgemmParams& p, hipStream_t stream) {
-    using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT>;
+    using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE>;
     p.tiles_d = ceil_div(p.D, TD);
     p.tiles_h = ceil_div(p.H, TH);
     p.tiles_w = ceil_div(p.W, TW);
@@ -386,7 +391,7 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
     p.ntiles = (int)nt;
     p.NKB = ceil_div(p.K, C::CB);
     p.vec_store = ((((uintptr_t)p.y) % (4 * sizeof(T))) == 0 && (p.ldy % 4) == 0) ? 1 : 0;
-    auto kern = igemm_fwd_kernel<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT>;
+    auto kern = igemm_fwd_kernel<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) !=
@@ -405,13 +410,13 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
     return MSSEG_OK;
 }
 
-template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES>
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int STRIDE = 1>
 int launch_nt(IgemmParams& p, hipStream_t stream) {
     const int cb = msseg_cout_block(p.M);
     switch (cb) {
-        case 16: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 1>(p, stream);
-        case 32: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 2>(p, stream);
-        case 48: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 3>(p, stream);
+        case 16: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 1, STRIDE>(p, stream);
+        case 32: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 2, STRIDE>(p, stream);
+        case 48: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 3, STRIDE>(p, stream);
     }
     MSSEG_FAIL(MSSEG_EINVAL, "igemm: bad cout block %d", cb);
 }
@@ -471,6 +476,22 @@ int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const floa
     return dtype == MSSEG_F32 ? launch_k3<float>(p, (hipStream_t)stream) : launch_k3<bf16_t>(p, (hipStream_t)stream);
 }
 
+int msseg_conv3d_k3s2_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                          int N, int ID, int IH, int IW, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    int rc = check_common(x, ldx, wp, y, ldy, dtype, esz);
+    if (rc) return rc;
+    if (N < 1 || ID < 1 || IH < 1 || IW < 1 || Cin < 1 || Cout < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3s2: bad shape");
+    if (Cin % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3s2: Cin=%d must be a multiple of %d", Cin, 16 / esz);
+    IgemmParams p{};
+    p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy;
+    p.N = N; p.ID = ID; p.IH = IH; p.IW = IW;
+    p.D = (ID - 1) / 2 + 1; p.H = (IH - 1) / 2 + 1; p.W = (IW - 1) / 2 + 1;
+    p.K = Cin; p.M = Cout;
+    return dtype == MSSEG_F32 ? launch_nt<float, 27, SRC_DIRECT, EPI_STORE, 2, 4, 8, 4, 2>(p, (hipStream_t)stream)
+                              : launch_nt<bf16_t, 27, SRC_DIRECT, EPI_STORE, 2, 4, 8, 4, 2>(p, (hipStream_t)stream);
+}
+
 int msseg_conv3d_k1_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                         long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream) {
     const int esz = dtype == MSSEG_F32 ? 4 : 2;
@@ -491,8 +512,7 @@ int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const 
     const int esz = dtype == MSSEG_F32 ? 4 : 2;
     if (!x || !wp || !y) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: null pointer");
     if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: bad dtype");
-    if (k < 1 || s < 1 || pd < 0 || Cin < 1 || Cin * k * k * k > 128)
-        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: Cin*k^3=%d must be <= 128", Cin * k * k * k);
+    if (k < 1 || s < 1 || pd < 0 || Cin < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: bad kernel geometry");
     const int OD = (ID + 2 * pd - k) / s + 1, OH = (IH + 2 * pd - k) / s + 1, OW = (IW + 2 * pd - k) / s + 1;
     if (OD < 1 || OH < 1 || OW < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: empty output");
     const long long NV = (long long)N * OD * OH * OW;

@@ -437,7 +437,7 @@ int msseg_conv3d_gather_wgrad(const void* x, long long ldx, const void* dy, long
     if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: bad dtype");
     const int esz = dtype == MSSEG_F32 ? 4 : 2;
     if (((uintptr_t)dy & 15) || (lddy * esz) % 16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: dy alignment");
-    if (k < 1 || s < 1 || pd < 0 || Cin * k * k * k > 128) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: bad kernel");
+    if (k < 1 || s < 1 || pd < 0) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: bad kernel");
     const int OD = (ID + 2 * pd - k) / s + 1, OH = (IH + 2 * pd - k) / s + 1, OW = (IW + 2 * pd - k) / s + 1;
     const long long NV = (long long)N * OD * OH * OW;
     if (OD < 1 || OH < 1 || OW < 1 || NV > 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: bad shape");

@@ -1,0 +1,87 @@
+"""One training epoch.  Signature, meter names and control flow of ``/root/reference/engine/train.py:14-128``;
+the per-step hard-Dice metric re-uses the reductions the fused DiceCE pass already produced (no second pass
+over the logits), and nothing here assumes CUDA-only APIs beyond the device the tensors live on."""
+from __future__ import annotations
+
+import math
+import sys
+
+import torch
+
+from .. import losses as L
+from ..utils import misc
+
+
+def _metric_update(metric_logger, criterion, outputs, labels, n_cls):
+    hard = getattr(criterion, "last", {}).get("hard") if hasattr(criterion, "last") else None
+    custom = getattr(criterion, "hard_dice", None)   # injection point (tests drive the loop with the CPU oracle)
+    if custom is not None:
+        scores, not_nans = custom(outputs.detach(), labels)
+    elif hard is not None and hard.shape[0] == outputs.shape[0]:
+        scores, not_nans = L.dice_from_counts(hard)
+    else:
+        scores, not_nans = L.dice_metric(outputs.detach(), labels)
+    scores, not_nans = scores.cpu(), not_nans.cpu()
+    class_means = torch.zeros(n_cls)
+    for c in range(n_cls):
+        cd = scores[:, c].nanmean() if not_nans[:, c].sum() > 0 else torch.tensor(float("nan"))
+        class_means[c] = cd
+        metric_logger.update(**{"class" + str(c) + "Dice": float(cd)})
+    return class_means.nanmean()
+
+
+def train_one_epoch(model, data_loader, optimizer, criterion, device, epoch, loss_scaler, cfg, log_writer=None):
+    model.train()
+    metric_logger = misc.MetricLogger(delimiter="  ")
+    for name in ["lr", "loss", "mDice"] + ["class" + str(c) + "Dice" for c in range(cfg.output_dim)]:
+        metric_logger.add_meter(name, misc.SmoothedValue(window_size=100, fmt="{value:.6f}"))
+    header = "Epoch: [{}]".format(epoch)
+    iters = len(data_loader)
+    optimizer.zero_grad()
+    amp_dtype = torch.bfloat16  # bf16 on MI355X: no loss scaling needed (the reference used fp16 + GradScaler)
+
+    for data_iter_step, batch in enumerate(metric_logger.log_every(data_loader, 20, header)):
+        torch.autograd.set_detect_anomaly(bool(getattr(cfg, "anomaly_detection", False)))
+        inputs = batch["image"].to(device, non_blocking=True)
+        labels = batch["label"].to(device, non_blocking=True)
+        aff_xyz = misc.get_affine_xyz(batch["image_meta_dict"]["original_affine"]).float().to(device, non_blocking=True)
+        crop_loc = None
+        for t in batch.get("image_transforms", []):
+            if t["class"][0] in ("RandCropByPosNegLabeld", "RandCropByClassesd"):
+                crop_loc = misc.get_rel_crop_loc(t)
+
+        outputs = model((inputs, crop_loc, aff_xyz))   # compute dtype is a property of the model (bf16 / fp32)
+        loss = criterion(outputs, labels)
+        loss_value = loss.item()
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            sys.exit(1)
+
+        loss_scaler.scale(loss).backward()
+        if cfg.gradient_clipping is not None:
+            loss_scaler.unscale_(optimizer)
+            if hasattr(optimizer, "clip_grad_norm_"):
+                optimizer.clip_grad_norm_(cfg.gradient_clipping)
+            else:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.gradient_clipping)
+        sync = getattr(optimizer, "sync_gradients", None)
+        if sync is not None:
+            sync()   # flat-buffer all-reduce (data parallel)
+        loss_scaler.step(optimizer)
+        loss_scaler.update()
+        optimizer.zero_grad()
+
+        mDice = _metric_update(metric_logger, criterion, outputs, labels, cfg.output_dim)
+        metric_logger.update(loss=loss_value)
+        metric_logger.update(mDice=mDice.item())
+        lr = optimizer.param_groups[0]["lr"]
+        metric_logger.update(lr=lr)
+        loss_value_reduce = misc.all_reduce_mean(loss_value)
+        if log_writer is not None:
+            epoch_1000x = int((data_iter_step / iters + epoch) * 1000)
+            log_writer.add_scalar("train_loss", loss_value_reduce, epoch_1000x)
+            log_writer.add_scalar("lr", lr, epoch_1000x)
+
+    metric_logger.synchronize_between_processes()
+    print("Training averaged stats:", metric_logger.log_all_average())
+    return {"train/" + k: meter.global_avg for k, meter in metric_logger.meters.items()}

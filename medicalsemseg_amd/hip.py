@@ -32,6 +32,14 @@ SIGNATURES = {
     "msseg_cout_block": ([_i], _i),
     "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_reduce_scratch_bytes": ([], _sz),
+    "msseg_conv3d_k3s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_zero_stuff2": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_window_attention_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_window_attention_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_layernorm_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _ll, _i, _f, _i, _vp], _i),
+    "msseg_layernorm_bwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _ll, _i, _i, _vp], _i),
+    "msseg_gelu_fwd": ([_vp, _vp, _ll, _i, _vp], _i),
+    "msseg_gelu_bwd": ([_vp, _vp, _vp, _ll, _i, _vp], _i),
     "msseg_conv3d_k1_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_gather_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_deconv_k2s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -524,3 +532,81 @@ def sw_gather(vol, win, start, cval=0.0):
     _ck(lib().msseg_sw_gather(_p(vol), _p(win), dt(win), Cc, VD, VH, VW, RD, RH, RW, int(start[0]), int(start[1]),
                               int(start[2]), float(cval), _stream()), "sw_gather")
     return win
+
+
+# --------------------------------------------------------------------------------------------
+# Swin pieces
+# --------------------------------------------------------------------------------------------
+def conv3d_k3s2(x, wp, bias, y, cin, cout):
+    _need_gpu(x, wp, y)
+    N, D, H, W = x.shape[:4]
+    _ck(lib().msseg_conv3d_k3s2_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, dt(x),
+                                    _stream()), "conv3d_k3s2_fwd")
+    return y
+
+
+def zero_stuff2(dy, out):
+    """dy [N,OD,OH,OW,C] -> out [N,ID,IH,IW,C] with out[:, ::2, ::2, ::2] = dy and zeros elsewhere."""
+    _need_gpu(dy, out)
+    N, OD, OH, OW, Cc = dy.shape
+    ID, IH, IW = out.shape[1:4]
+    _ck(lib().msseg_zero_stuff2(_p(dy), ld(dy), _p(out), ld(out), N, OD, OH, OW, ID, IH, IW, Cc, dt(dy), _stream()),
+        "zero_stuff2")
+    return out
+
+
+def window_attention_fwd(qkv, qkv_bias, table, out, heads, ws, shift):
+    """qkv [B,S,H,W,3C] contiguous -> out [B,S,H,W,C]; returns lse for the backward."""
+    _need_gpu(qkv, table, out)
+    assert qkv.is_contiguous() and out.is_contiguous()
+    B, S, H, W, C3 = qkv.shape
+    Cc = C3 // 3
+    nW = -(-S // ws) * -(-H // ws) * -(-W // ws)
+    lse = torch.empty(B * nW, heads, ws ** 3, dtype=torch.float32, device=qkv.device)
+    _ck(lib().msseg_window_attention_fwd(_p(qkv), _p(qkv_bias), _p(table), _p(out), _p(lse), B, S, H, W, Cc, heads, ws,
+                                         shift, dt(qkv), _stream()), "window_attention_fwd")
+    return lse
+
+
+def window_attention_bwd(qkv, qkv_bias, table, out, lse, dout, dqkv, dtable, heads, ws, shift):
+    _need_gpu(qkv, table, out, lse, dout, dqkv)
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
+    B, S, H, W, C3 = qkv.shape
+    _ck(lib().msseg_window_attention_bwd(_p(qkv), _p(qkv_bias), _p(table), _p(out), _p(lse), _p(dout), _p(dqkv),
+                                         _p(dtable), B, S, H, W, C3 // 3, heads, ws, shift, dt(qkv), _stream()),
+        "window_attention_bwd")
+    return dqkv
+
+
+def layernorm_fwd(x, gamma, beta, y, eps=1e-5, save=True):
+    _need_gpu(x, y)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    _ck(lib().msseg_layernorm_fwd(_p(x), ld(x), _p(gamma), _p(beta), _p(y), ld(y), _p(mean), _p(rstd), rows, Cc, eps,
+                                  dt(x), _stream()), "layernorm_fwd")
+    return mean, rstd
+
+
+def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma=None, dbeta=None):
+    _need_gpu(x, dy, dx)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    _ck(lib().msseg_layernorm_bwd(_p(x), ld(x), _p(gamma), _p(mean), _p(rstd), _p(dy), ld(dy), _p(dx), ld(dx),
+                                  _p(dgamma), _p(dbeta), rows, Cc, dt(x), _stream()), "layernorm_bwd")
+    return dx
+
+
+def gelu_fwd(x, y):
+    _need_gpu(x, y)
+    assert x.is_contiguous() and y.is_contiguous()
+    _ck(lib().msseg_gelu_fwd(_p(x), _p(y), x.numel(), dt(x), _stream()), "gelu_fwd")
+    return y
+
+
+def gelu_bwd(x, dy, dx):
+    _need_gpu(x, dy, dx)
+    assert x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous()
+    _ck(lib().msseg_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), dt(x), _stream()), "gelu_bwd")
+    return dx

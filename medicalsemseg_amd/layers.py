@@ -120,11 +120,21 @@ class Conv1:
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.cache = PackedCache()
 
-    def fwd(self, x, out=None):
+    def _gather(self, dtype):
+        return self.cin % (8 if dtype == torch.bfloat16 else 4) != 0
+
+    def fwd(self, x, out=None, want_stats=False):
         dtype = x.dtype
         y = out if out is not None else _empty_like_vol(x, self.cout)
-        wp = self.cache.get(self.w, dtype, "f", lambda: hip.pack_conv_k1(self.w.detach().reshape(self.cout, self.cin), dtype))
-        hip.conv3d_k1(x, wp, self.b, y, self.cin, self.cout)
+        if self._gather(dtype):
+            wp = self.cache.get(self.w, dtype, "g", lambda: hip.pack_conv_gather(self.w.detach(), dtype))
+            hip.conv3d_gather(x, wp, self.b, y, self.cin, self.cout, 1, 1, 0)
+        else:
+            wp = self.cache.get(self.w, dtype, "f",
+                                lambda: hip.pack_conv_k1(self.w.detach().reshape(self.cout, self.cin), dtype))
+            hip.conv3d_k1(x, wp, self.b, y, self.cin, self.cout)
+        if want_stats:
+            return y, hip.channel_stats(y)
         return y
 
     def bwd(self, x, dy, need_dx=True, dy_channels=None):
@@ -132,12 +142,17 @@ class Conv1:
         dtype = x.dtype
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
-            hip.conv3d_k1_wgrad(x, dy[..., :self.cout], g, self.cin, self.cout, acc)
+            if self._gather(dtype):
+                hip.conv3d_gather_wgrad(x, dy[..., :self.cout], g, self.cin, self.cout, 1, 1, 0, acc)
+            else:
+                hip.conv3d_k1_wgrad(x, dy[..., :self.cout], g, self.cin, self.cout, acc)
         if self.b is not None and self.b.requires_grad:
             g, acc = _grad_buf(self.b)
             hip.channel_sum(dy[..., :self.cout], g, acc)
         if not need_dx:
             return None
+        if self._gather(dtype):
+            raise NotImplementedError("input gradient of a few-channel 1x1 conv is never needed on this path")
         wp = self.cache.get(self.w, dtype, "d",
                             lambda: hip.pack_conv_k1(self.w.detach().reshape(self.cout, self.cin), dtype, dgrad=True))
         dx = _empty_like_vol(dy, self.cin)
@@ -226,3 +241,68 @@ def maxpool_fwd(x):
     N, D, H, W, C = x.shape
     y = torch.empty(N, D // 2, H // 2, W // 2, C, dtype=x.dtype, device=x.device)
     return hip.maxpool2_fwd(x, y)
+
+
+class ResBlock:
+    """MONAI UnetResBlock (stride 1): lrelu(IN(conv2(lrelu(IN(conv1(x))))) + r), r = IN(conv3_1x1(x)) iff in != out
+    else x; convs bias-free, InstanceNorm affine=False, LeakyReLU(0.01)  (SURVEY.md row A3)."""
+
+    def __init__(self, conv1_w, conv2_w, conv3_w=None, slope=0.01):
+        self.c1, self.c2 = Conv3(conv1_w, None), Conv3(conv2_w, None)
+        self.c3 = Conv1(conv3_w, None) if conv3_w is not None else None
+        self.n1, self.n2 = InstNormAct(None, None, slope), InstNormAct(None, None, slope)
+        self.n3 = InstNormAct(None, None, 1.0) if conv3_w is not None else None
+
+    def fwd(self, x, out=None):
+        y1, s1 = self.c1.fwd(x, want_stats=True)
+        a1, s1 = self.n1.fwd(y1, stats=s1)
+        y2, s2 = self.c2.fwd(a1, want_stats=True)
+        if self.c3 is not None:
+            y3, s3 = self.c3.fwd(x, want_stats=True)
+            r, s3 = self.n3.fwd(y3, stats=s3)
+        else:
+            y3 = s3 = None
+            r = x
+        o, s2 = self.n2.fwd(y2, out, residual=r, stats=s2)
+        return o, (x, y1, s1, a1, y2, s2, y3, s3, r, o)
+
+    def bwd(self, saved, do, need_dx=True):
+        x, y1, s1, a1, y2, s2, y3, s3, r, o = saved
+        dy2, dres = self.n2.bwd(y2, s2, o, do, want_dres=True)
+        da1 = self.c2.bwd(a1, dy2, True)
+        dy1 = self.n1.bwd(y1, s1, a1, da1)
+        dx = self.c1.bwd(x, dy1, need_dx)
+        if self.c3 is not None:
+            dy3 = self.n3.bwd(y3, s3, r, dres)
+            dx3 = self.c3.bwd(x, dy3, need_dx)
+        else:
+            dx3 = dres
+        if not need_dx:
+            return None
+        return hip.add(dx, dx3, dx)
+
+
+class UpBlock:
+    """MONAI UnetrUpBlock: up = ConvT(k = s)(x) (bias-free); ResBlock(cat([up, skip]))  (row A4).  The transposed conv
+    and the skip producer write straight into the two halves of the concat buffer."""
+
+    def __init__(self, transp_w, conv1_w, conv2_w, conv3_w, slope=0.01):
+        self.up = Deconv2(transp_w, None)
+        self.res = ResBlock(conv1_w, conv2_w, conv3_w, slope)
+        self.cout = transp_w.shape[1]
+
+    def alloc_cat(self, x):
+        N, D, H, W, _ = x.shape
+        return torch.empty(N, 2 * D, 2 * H, 2 * W, 2 * self.cout, dtype=x.dtype, device=x.device)
+
+    def fwd(self, x, cat):
+        """cat[..., cout:] must already hold the skip; returns (out, saved)."""
+        self.up.fwd(x, cat[..., :self.cout])
+        o, s = self.res.fwd(cat)
+        return o, (x, s)
+
+    def bwd(self, saved, do):
+        x, s = saved
+        dcat = self.res.bwd(s, do, True)
+        dx = self.up.bwd(x, dcat[..., :self.cout], True)
+        return dx, dcat[..., self.cout:]

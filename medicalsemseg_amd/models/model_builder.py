@@ -1,0 +1,53 @@
+"""``build_model(cfg) -> nn.Module``: the reference's model factory (``/root/reference/models/model_builder.py:14-242``)
+for the models on the hot path.
+
+* ``cfg.model in {'UNet', 'UNetSmall'}`` -- MONAI BasicUNet topology (BASELINE.json configs 1-3; the reference has no
+  UNet).
+* ``cfg.model == 'nnFormerUNETR'`` -- ``SwinTransformerNNFormer`` encoder + ``SwinUNETRCustom`` decoder, the branch
+  at ``model_builder.py:15-66``.
+Every returned module obeys the engine contract ``model((vol, rel_crop_loc, affine_xyz)) -> logits`` and keeps the
+reference's / MONAI's state-dict key layout.  ``cfg.compute_dtype``: 'bf16' (default) or 'f32'.
+"""
+from __future__ import annotations
+
+import torch
+
+from .unet import UNET_FEATURES, UNet
+
+OUT_OF_SCOPE = ("SwInception", "SwinDepth", "SwinSegFormer", "SegFormer3D", "GCViTUNETR", "FocalNetUNETR")
+
+
+def _dtype(cfg):
+    name = str(getattr(cfg, "compute_dtype", "bf16")).lower()
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if name in ("f32", "fp32", "float32"):
+        return torch.float32
+    raise ValueError(f"compute_dtype must be bf16 or f32, got {name}")
+
+
+def _t3(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+def build_model(cfg):
+    name = cfg.model
+    if name in UNET_FEATURES:
+        return UNet(cfg.in_chans, cfg.output_dim, UNET_FEATURES[name], compute_dtype=_dtype(cfg))
+    if name == "nnFormerUNETR":
+        from .swin_unetr import SwinTransformerNNFormer, SwinUNETRCustom
+        for flag in ("learned_cls_vectors", "rel_pos_bias_affine", "rel_crop_pos_emb", "abs_pos_emb", "global_token"):
+            if getattr(cfg, flag, False):
+                raise NotImplementedError(f"--{flag} is outside the hot-path scope of this build (SURVEY.md section 2)")
+        ws = cfg.window_size if isinstance(cfg.window_size, (tuple, list)) else (cfg.window_size,) * len(cfg.depths)
+        encoder = SwinTransformerNNFormer(pretrain_img_size=_t3(cfg.vol_size), patch_size=_t3(cfg.patch_size),
+                                          in_chans=cfg.in_chans, embed_dim=cfg.hidden_dim, depths=tuple(cfg.depths),
+                                          num_heads=tuple(cfg.num_heads), window_size=tuple(ws), qkv_bias=cfg.qkv_bias,
+                                          mlp_ratio=getattr(cfg, "mlp_ratio", 4.0), compute_dtype=_dtype(cfg))
+        return SwinUNETRCustom(encoder, in_channels=cfg.in_chans, out_channels=cfg.output_dim,
+                               img_size=_t3(cfg.vol_size), hidden_size=cfg.hidden_dim, patch_size=_t3(cfg.patch_size),
+                               compute_dtype=_dtype(cfg))
+    if name in OUT_OF_SCOPE:
+        raise NotImplementedError(f"model '{name}' is a research variant outside this build's hot-path scope "
+                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR']")
+    raise ValueError(f"unknown cfg.model '{name}'")

@@ -1,0 +1,296 @@
+"""Swin-UNETR on the HIP kernels: ``SwinTransformerNNFormer`` encoder + ``SwinUNETRCustom`` decoder.
+
+Encoder: mirror of ``/root/reference/models/backbones/swin_nnformer.py`` (``SwinTransformerNNFormer`` :478-659,
+``BasicLayer`` :315-405, ``SwinTransformerBlock`` :199-289, ``WindowAttention`` :67-196, ``PatchMerging`` :292-312) and
+``PatchEmbed3D`` (``models/blocks/patch_embeddings.py:86-133``), default code path only.  Decoder: mirror of
+``/root/reference/models/segmentors/swin_unetr.py:20-147`` with MONAI's ``UnetrBasicBlock / UnetrUpBlock /
+UnetOutBlock``.  Parameter names equal the reference's state-dict keys.
+
+Everything stays channels-last: a token tensor ``[B, L, C]`` IS the volume ``[B, S, H, W, C]``, so the reference's
+flatten/transpose/permute/contiguous copies, pad, roll and window partition/reverse do not exist here -- the
+window-attention kernel does them by addressing.  The encoder is a chain of single-kernel autograd ops
+(``ops.py``); the decoder (93 % of the FLOPs) is one autograd node over ``layers.py`` with concat buffers written in
+place.
+"""
+from __future__ import annotations
+
+from math import ceil
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import hip, ops
+from ..layers import Conv1, ResBlock, UpBlock
+from .unet import LOGIT_LD
+
+
+def _rel_index(ws: int) -> torch.Tensor:
+    r = torch.arange(ws)
+    c = torch.stack(torch.meshgrid(r, r, r, indexing="ij")).flatten(1)
+    rel = c[:, :, None] - c[:, None, :] + (ws - 1)
+    m = 2 * ws - 1
+    return rel[0] * m * m + rel[1] * m + rel[2]
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _WindowAttention(nn.Module):
+    def __init__(self, dim, ws, heads, qkv_bias):
+        super().__init__()
+        self.ws, self.heads = ws, heads
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) ** 3, heads))
+        self.register_buffer("relative_position_index", _rel_index(ws))
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, res, heads, ws, shift, mlp_ratio, qkv_bias, drop_path):
+        super().__init__()
+        self.res = tuple(res)
+        if min(self.res) <= ws:          # swin_nnformer.py:213-216
+            shift, ws = 0, min(self.res)
+        self.ws, self.shift, self.heads, self.drop_path = ws, shift, heads, float(drop_path)
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = _WindowAttention(dim, ws, heads, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+    def _dp(self, x):
+        if self.drop_path == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_path   # per-sample stochastic depth (models/layers/drop_path.py:15-45)
+        mask = torch.empty(x.shape[0], 1, 1, 1, 1, device=x.device, dtype=torch.float32).bernoulli_(keep) / keep
+        return x * mask.to(x.dtype)
+
+    def forward(self, x):
+        a = self.attn
+        xn = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias)
+        y = ops.WindowAttnFn.apply(qkv, a.qkv.bias, a.relative_position_bias_table, self.heads, self.ws, self.shift)
+        y = ops.linear(y, a.proj.weight, a.proj.bias)
+        x = ops.add(x, self._dp(y))
+        y = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        y = ops.gelu(ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
+        y = ops.linear(y, self.mlp.fc2.weight, self.mlp.fc2.bias)
+        return ops.add(x, self._dp(y))
+
+
+class _PatchMerging(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.reduction = nn.Conv3d(dim, dim * 2, kernel_size=3, stride=2, padding=1)
+        self.norm = nn.LayerNorm(dim)
+
+    def forward(self, x):
+        g = ops.layer_norm(ops.gelu(x), self.norm.weight, self.norm.bias, self.norm.eps)
+        return ops.Conv3Fn.apply(g, self.reduction.weight, self.reduction.bias, 2)
+
+
+class _BasicLayer(nn.Module):
+    def __init__(self, dim, res, depth, heads, ws, mlp_ratio, qkv_bias, drop_path):
+        super().__init__()
+        self.blocks = nn.ModuleList([_Block(dim, res, heads, ws, 0 if i % 2 == 0 else ws // 2, mlp_ratio, qkv_bias,
+                                            drop_path[i]) for i in range(depth)])
+        self.downsample = _PatchMerging(dim)
+
+    def forward(self, x):
+        for b in self.blocks:
+            x = b(x)
+        return self.downsample(x)
+
+
+class _PatchEmbed3D(nn.Module):
+    def __init__(self, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.patch_size = tuple(patch_size)
+        if len(set(self.patch_size)) != 1:
+            raise NotImplementedError("anisotropic patch sizes are not implemented")
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x_cl):
+        y = ops.PatchConvFn.apply(x_cl, self.proj.weight, self.proj.bias, self.patch_size[0])
+        return ops.layer_norm(y, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class SwinTransformerNNFormer(nn.Module):
+    """returns the 5 feature volumes channels-last: [C@R, 2C@R/2, 4C@R/4, 8C@R/8, 16C@R/16] (R = vol / patch)."""
+
+    def __init__(self, pretrain_img_size=(96, 96, 96), patch_size=(2, 2, 2), in_chans=1, embed_dim=48,
+                 depths: Sequence[int] = (2, 2, 2, 2), num_heads: Sequence[int] = (3, 6, 12, 24),
+                 window_size: Sequence[int] = (6, 6, 6, 3), mlp_ratio=4.0, qkv_bias=True, drop_path_rate=0.2,
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.num_layers, self.embed_dim, self.compute_dtype = len(depths), embed_dim, compute_dtype
+        self.patch_embed = _PatchEmbed3D(patch_size, in_chans, embed_dim)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            res = tuple(pretrain_img_size[d] // patch_size[d] // 2 ** i for d in range(3))
+            self.layers.append(_BasicLayer(embed_dim * 2 ** i, res, depths[i], num_heads[i], window_size[i], mlp_ratio,
+                                           qkv_bias, dpr[sum(depths[:i]):sum(depths[:i + 1])]))
+        self.num_features = [embed_dim * 2 ** (i + 1) for i in range(self.num_layers)]
+        for i in range(self.num_layers):
+            self.add_module(f"norm{i}", nn.LayerNorm(self.num_features[i]))
+
+    def forward(self, inp):
+        vol = inp[0] if isinstance(inp, (tuple, list)) else inp
+        if not vol.is_cuda:
+            raise RuntimeError("SwinTransformerNNFormer runs on the GPU only (no CPU fallback)")
+        B, Cin, D, H, W = vol.shape
+        p = self.patch_embed.patch_size[0]
+        if D % p or H % p or W % p:
+            raise ValueError("volume must be a multiple of the patch size")
+        x_cl = torch.empty(B, D, H, W, Cin, dtype=self.compute_dtype, device=vol.device)
+        hip.to_channels_last(vol if vol.dtype in (torch.float32, torch.bfloat16) else vol.float(), x_cl)
+        x = self.patch_embed(x_cl)
+        feats = [x]
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            n = getattr(self, f"norm{i}")
+            feats.append(ops.layer_norm(x, n.weight, n.bias, n.eps))   # norm of the DOWNSAMPLED tensor (:653-658)
+        return feats, x_cl
+
+
+# ------------------------------------------------------------------------------------------------------------
+# decoder
+# ------------------------------------------------------------------------------------------------------------
+class _ConvOnly(nn.Sequential):
+    def __init__(self, cin, cout, k, transposed=False, bias=False):
+        super().__init__()
+        if transposed:
+            self.add_module("conv", nn.ConvTranspose3d(cin, cout, kernel_size=k, stride=k, bias=bias))
+        else:
+            self.add_module("conv", nn.Conv3d(cin, cout, kernel_size=k, padding=(k - 1) // 2, bias=bias))
+
+
+class _UnetResBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = _ConvOnly(cin, cout, 3)
+        self.conv2 = _ConvOnly(cout, cout, 3)
+        if cin != cout:
+            self.conv3 = _ConvOnly(cin, cout, 1)
+
+    def op(self):
+        c3 = self.conv3.conv.weight if hasattr(self, "conv3") else None
+        return ResBlock(self.conv1.conv.weight, self.conv2.conv.weight, c3)
+
+
+class _UnetrBasicBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.layer = _UnetResBlock(cin, cout)
+
+
+class _UnetrUpBlock(nn.Module):
+    def __init__(self, cin, cout, up_k):
+        super().__init__()
+        if up_k != 2:
+            raise NotImplementedError("only 2x transposed-conv upsampling (patch_size 2) is implemented")
+        self.transp_conv = _ConvOnly(cin, cout, up_k, transposed=True)
+        self.conv_block = _UnetResBlock(cout + cout, cout)
+
+    def op(self):
+        b = self.conv_block
+        return UpBlock(self.transp_conv.conv.weight, b.conv1.conv.weight, b.conv2.conv.weight, b.conv3.conv.weight)
+
+
+class _UnetOutBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = _ConvOnly(cin, cout, 1, bias=True)
+
+
+class SwinUNETRCustom(nn.Module):
+    def __init__(self, encoder, in_channels, out_channels, img_size=(96, 96, 96), hidden_size=48, patch_size=(2, 2, 2),
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.encoder, self.out_channels, self.compute_dtype = encoder, out_channels, compute_dtype
+        hs = hidden_size
+        ps = patch_size[0] if isinstance(patch_size, (tuple, list)) else patch_size
+        self.unet_encoders = nn.ModuleList([_UnetrBasicBlock(in_channels, hs), _UnetrBasicBlock(hs, hs)])
+        self.unet_decoders = nn.ModuleList([_UnetrUpBlock(hs, hs, ps)])
+        for i in range(encoder.num_layers):
+            self.unet_encoders.append(_UnetrBasicBlock(hs * 2 ** (i + 1), hs * 2 ** (i + 1)))
+            self.unet_decoders.append(_UnetrUpBlock(hs * 2 ** (i + 1), hs * 2 ** i, 2))
+        self.out = _UnetOutBlock(hs, out_channels)
+        self._build_ops()
+
+    def _build_ops(self):
+        self._enc_ops = [m.layer.op() for m in self.unet_encoders]
+        self._dec_ops = [m.op() for m in self.unet_decoders]
+        self._out_op = Conv1(self.out.conv.conv.weight, self.out.conv.conv.bias)
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._build_ops()
+        return r
+
+    def forward(self, x_in):
+        if not isinstance(x_in, (tuple, list)):
+            x_in = (x_in, None, None)
+        feats, x_cl = self.encoder(x_in)
+        dec_params = [p for m in (self.unet_encoders, self.unet_decoders, self.out) for p in m.parameters()]
+        return _DecoderFn.apply(self, x_cl, len(feats), *feats, *dec_params)
+
+
+class _DecoderFn(torch.autograd.Function):
+    """x = dec[-1](enc[-1](z[-1]), enc[-2](z[-2])); ... ; x = dec[0](x, enc[0](x_in)); out(x)
+    (/root/reference/models/segmentors/swin_unetr.py:138-147)"""
+
+    @staticmethod
+    def forward(ctx, net: SwinUNETRCustom, x_cl, nf, *rest):
+        feats = [f.contiguous() for f in rest[:nf]]
+        E, Dd = net._enc_ops, net._dec_ops
+        L = len(Dd)                      # number of up blocks = num_layers + 1
+        saved = {"enc": [None] * (L + 1), "dec": [None] * L}
+        # top of the pyramid
+        top, saved["enc"][L] = E[L].fwd(feats[L - 1])
+        x = top
+        for k in range(L - 1, -1, -1):   # decoder k consumes skip enc[k](source k)
+            src = feats[k - 1] if k >= 1 else x_cl
+            cat = Dd[k].alloc_cat(x)
+            cout = Dd[k].cout
+            _, saved["enc"][k] = E[k].fwd(src, out=cat[..., cout:])
+            x, saved["dec"][k] = Dd[k].fwd(x, cat)
+        N, D, H, W, _ = x.shape
+        logits_cl = torch.empty(N, D, H, W, LOGIT_LD, dtype=x.dtype, device=x.device)
+        net._out_op.fwd(x, logits_cl[..., :net.out_channels])
+        logits = torch.empty(N, net.out_channels, D, H, W, dtype=torch.float32, device=x.device)
+        hip.to_channels_first(logits_cl[..., :net.out_channels], logits)
+        if any(ctx.needs_input_grad):
+            ctx.net, ctx.saved, ctx.last, ctx.nf, ctx.n_in = net, saved, x, nf, 3 + len(rest)
+            ctx.feat_needs = [ctx.needs_input_grad[3 + i] for i in range(nf)]
+        ctx.set_materialize_grads(False)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        net, saved, nf = ctx.net, ctx.saved, ctx.nf
+        if dlogits is None:
+            return (None,) * ctx.n_in
+        E, Dd = net._enc_ops, net._dec_ops
+        L = len(Dd)
+        N, C, D, H, W = dlogits.shape
+        dl = torch.zeros(N, D, H, W, LOGIT_LD, dtype=net.compute_dtype, device=dlogits.device)
+        hip.to_channels_last(dlogits.contiguous(), dl[..., :C])
+        g = net._out_op.bwd(ctx.last, dl, True, dy_channels=LOGIT_LD)
+        dfeats = [None] * nf
+        for k in range(0, L):
+            g, dskip = Dd[k].bwd(saved["dec"][k], g)
+            need = k >= 1 and ctx.feat_needs[k - 1]
+            d = E[k].bwd(saved["enc"][k], dskip, need_dx=need)
+            if k >= 1:
+                dfeats[k - 1] = d
+        dfeats[L - 1] = E[L].bwd(saved["enc"][L], g, need_dx=ctx.feat_needs[L - 1])
+        ctx.saved = None
+        return (None, None, None, *dfeats) + (None,) * (ctx.n_in - 3 - nf)

@@ -1,0 +1,214 @@
+"""``torch.autograd.Function`` wrappers of single HIP ops on channels-last tensors ``[B, S, H, W, C]``.
+
+Used by the Swin encoder (``models/swin_unetr.py``), whose block algebra is a chain of small ops; the conv-heavy
+networks (UNet, the UNETR decoder) use whole-network functions over ``layers.py`` instead.  Every forward/backward
+here is one or two kernel launches through the C ABI; there is no torch arithmetic on activations.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hip
+
+
+def _c(x):
+    return x if x.is_contiguous() else x.contiguous()
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b on the last dim (nn.Linear): the 1x1x1 igemm on tokens."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _c(x)
+        cout, cin = weight.shape
+        T = x.dtype
+        wp = hip.pack_conv_k1(weight.detach().contiguous(), T)
+        y = torch.empty(x.shape[:-1] + (cout,), dtype=T, device=x.device)
+        hip.conv3d_k1(x, wp, bias, y, cin, cout)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _c(dy)
+        cout, cin = weight.shape
+        T = x.dtype
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wpd = hip.pack_conv_k1(weight.detach().contiguous(), T, dgrad=True)
+            dx = torch.empty_like(x)
+            hip.conv3d_k1(dy, wpd, None, dx, cout, cin)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            hip.conv3d_k1_wgrad(x, dy, dw, cin, cout)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(cout, dtype=torch.float32, device=x.device)
+            hip.channel_sum(dy, db)
+        return dx, dw, db
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        y = torch.empty_like(x)
+        mean, rstd = hip.layernorm_fwd(x, gamma, beta, y, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dg = torch.zeros_like(gamma) if ctx.needs_input_grad[1] else None
+        db = torch.zeros_like(gamma) if ctx.needs_input_grad[1] else None
+        hip.layernorm_bwd(x, gamma, mean, rstd, dy, dx, dg, db)
+        return dx, dg, db, None
+
+
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return hip.gelu_fwd(x, torch.empty_like(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        return hip.gelu_bwd(x, _c(dy), torch.empty_like(x))
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        return hip.add(a, b, torch.empty_like(a))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class WindowAttnFn(torch.autograd.Function):
+    """shifted-window attention core on a token volume: qkv [B,S,H,W,3C] -> [B,S,H,W,C]"""
+
+    @staticmethod
+    def forward(ctx, qkv, qkv_bias, table, heads, ws, shift):
+        qkv = _c(qkv)
+        B, S, H, W, C3 = qkv.shape
+        out = torch.empty(B, S, H, W, C3 // 3, dtype=qkv.dtype, device=qkv.device)
+        qb = qkv_bias.detach() if qkv_bias is not None else None
+        tab = table.detach().contiguous()
+        lse = hip.window_attention_fwd(qkv, qb, tab, out, heads, ws, shift)
+        ctx.save_for_backward(qkv, qb, tab, out, lse)
+        ctx.cfg = (heads, ws, shift)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, qb, tab, out, lse = ctx.saved_tensors
+        heads, ws, shift = ctx.cfg
+        dqkv = torch.empty_like(qkv)
+        dtable = torch.zeros_like(tab) if ctx.needs_input_grad[2] else None
+        hip.window_attention_bwd(qkv, qb, tab, out, lse, _c(dout), dqkv, dtable, heads, ws, shift)
+        # gradient w.r.t. qkv_bias through PADDED tokens (only when the grid is not a window multiple) is dropped
+        return dqkv, None, dtable, None, None, None
+
+
+class Conv3Fn(torch.autograd.Function):
+    """Conv3d k3 p1, stride 1 or 2 (+bias) on [B,D,H,W,C]"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        x = _c(x)
+        cout, cin = weight.shape[0], weight.shape[1]
+        T = x.dtype
+        B, D, H, W, _ = x.shape
+        wp = hip.pack_conv_k3(weight.detach().contiguous(), T)
+        if stride == 1:
+            y = torch.empty(B, D, H, W, cout, dtype=T, device=x.device)
+            hip.conv3d_k3(x, wp, bias, y, cin, cout)
+        else:
+            y = torch.empty(B, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1, cout, dtype=T, device=x.device)
+            hip.conv3d_k3s2(x, wp, bias, y, cin, cout)
+        ctx.save_for_backward(x, weight)
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _c(dy)
+        cout, cin = weight.shape[0], weight.shape[1]
+        T = x.dtype
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(cout, dtype=torch.float32, device=x.device)
+            hip.channel_sum(dy, db)
+        if ctx.stride == 2:   # stride-1 problems on the zero-stuffed gradient
+            dyz = torch.empty(x.shape[:-1] + (cout,), dtype=T, device=x.device)
+            hip.zero_stuff2(dy, dyz)
+            dy = dyz
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wpd = hip.pack_conv_k3(weight.detach().contiguous(), T, dgrad=True)
+            dx = torch.empty_like(x)
+            hip.conv3d_k3(dy, wpd, None, dx, cout, cin)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            hip.conv3d_k3_wgrad(x, dy, dw, cin, cout)
+        return dx, dw, db, None
+
+
+class PatchConvFn(torch.autograd.Function):
+    """Conv3d with kernel = stride = k, no padding, few input channels (PatchEmbed3D.proj)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, k):
+        x = _c(x)
+        cout, cin = weight.shape[0], weight.shape[1]
+        T = x.dtype
+        B, D, H, W, _ = x.shape
+        wp = hip.pack_conv_gather(weight.detach().contiguous(), T)
+        y = torch.empty(B, D // k, H // k, W // k, cout, dtype=T, device=x.device)
+        hip.conv3d_gather(x, wp, bias, y, cin, cout, k, k, 0)
+        ctx.save_for_backward(x, weight)
+        ctx.k, ctx.has_bias = k, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _c(dy)
+        cout, cin = weight.shape[0], weight.shape[1]
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            hip.conv3d_gather_wgrad(x, dy, dw, cin, cout, ctx.k, ctx.k, 0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(cout, dtype=torch.float32, device=x.device)
+            hip.channel_sum(dy, db)
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the input volume is not needed on this path")
+        return None, dw, db, None
+
+
+def linear(x, weight, bias=None):
+    return LinearFn.apply(x, weight, bias)
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+def gelu(x):
+    return GeluFn.apply(x)
+
+
+def add(a, b):
+    return AddFn.apply(a, b)

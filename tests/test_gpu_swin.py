@@ -1,0 +1,144 @@
+"""GPU parity of the Swin path: HIP window attention / Swin block / encoder against the golden vectors produced by
+the REFERENCE's own modules (tests/golden, oracle/gen_golden.py), and the whole Swin-UNETR against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import det_fill_, det_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _rel(a, b):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else a
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def _windows_to_volume(xw, ws, shift):
+    """[8, N, C] windows of the SHIFTED (2ws)^3 grid -> unshifted volume [1, 2ws, 2ws, 2ws, C]"""
+    from oracle.swin import window_reverse
+    C = xw.shape[-1]
+    vol = window_reverse(xw.reshape(8, ws, ws, ws, C), ws, 2 * ws, 2 * ws, 2 * ws)
+    return torch.roll(vol, shifts=(shift, shift, shift), dims=(1, 2, 3))
+
+
+def _volume_to_windows(vol, ws, shift):
+    from oracle.swin import window_partition
+    v = torch.roll(vol, shifts=(-shift, -shift, -shift), dims=(1, 2, 3))
+    return window_partition(v, ws).reshape(8, ws ** 3, -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag,dim,ws,heads", [("h3w6", 48, 6, 3), ("h24w3", 384, 3, 24)])
+def test_window_attention_vs_reference_golden(golden_dir, dtype, tag, dim, ws, heads):
+    from medicalsemseg_amd import ops
+    from medicalsemseg_amd.models.swin_unetr import _WindowAttention
+    g = _load(golden_dir, f"swin_attn_{tag}.npz")
+    m = _WindowAttention(dim, ws, heads, True)
+    det_fill_(m, "attn_" + tag)
+    m = m.to(DEV)
+    N = ws ** 3
+    xw = det_tensor("attn_x_" + tag, (8, N, dim))
+    rw = det_tensor("attn_r_" + tag, (8, N, dim))
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    for mk, shift in (("nomask", 0), ("mask", ws // 2)):
+        x = _windows_to_volume(xw, ws, shift).to(DEV, dtype).requires_grad_(True)
+        r = _windows_to_volume(rw, ws, shift).to(DEV, dtype)
+        for p in m.parameters():
+            p.grad = None
+        qkv = ops.linear(x, m.qkv.weight, m.qkv.bias)
+        y = ops.WindowAttnFn.apply(qkv, m.qkv.bias, m.relative_position_bias_table, heads, ws, shift)
+        y = ops.linear(y, m.proj.weight, m.proj.bias)
+        (y.float() * r.float()).sum().backward()
+        assert _rel(_volume_to_windows(y.detach().float().cpu(), ws, shift), g[f"y_{mk}"]) < tol
+        assert _rel(_volume_to_windows(x.grad.float().cpu(), ws, shift), g[f"dx_{mk}"]) < tol
+        assert _rel(m.relative_position_bias_table.grad, g[f"dtable_{mk}"]) < (1e-3 if dtype == torch.float32 else 5e-2)
+        if f"dqkvw_{mk}" in g.files:
+            assert _rel(m.qkv.weight.grad, g[f"dqkvw_{mk}"]) < (1e-3 if dtype == torch.float32 else 5e-2)
+
+
+@pytest.mark.parametrize("shift", [0, 3])
+def test_swin_block_vs_reference_golden(golden_dir, shift):
+    from medicalsemseg_amd.models.swin_unetr import _Block
+    g = _load(golden_dir, "swin_block.npz")
+    m = _Block(48, (12, 12, 12), 3, 6, shift, 4.0, True, 0.0)
+    det_fill_(m, "blk")
+    m = m.to(DEV)
+    x = det_tensor("blk_x", (2, 12 ** 3, 48)).reshape(2, 12, 12, 12, 48).to(DEV).requires_grad_(True)
+    y = m(x)
+    assert _rel(y.reshape(2, -1, 48), g[f"y_shift{shift}"]) < 2e-4
+    if shift:
+        r = det_tensor("blk_r", (2, 12 ** 3, 48)).reshape(2, 12, 12, 12, 48).to(DEV)
+        (y * r).sum().backward()
+        assert _rel(x.grad.reshape(2, -1, 48), g["dx_shift3"]) < 1e-3
+
+
+@pytest.mark.parametrize("tag,vol", [("v24", (24, 24, 24)), ("v20", (20, 20, 20))])
+def test_swin_encoder_vs_reference_golden(golden_dir, tag, vol):
+    from medicalsemseg_amd.models.swin_unetr import SwinTransformerNNFormer
+    g = _load(golden_dir, f"swin_encoder_{tag}.npz")
+    m = SwinTransformerNNFormer(vol, (2, 2, 2), 1, 32, (2, 2), (2, 4), (6, 3), drop_path_rate=0.0,
+                                compute_dtype=torch.float32)
+    det_fill_(m, "enc")
+    m = m.to(DEV)
+    x = det_tensor("enc_x_" + tag, (2, 1) + vol).to(DEV)
+    feats, _ = m((x, None, None))
+    loss = 0
+    for i, f in enumerate(feats):
+        ref = g[f"out{i}"]
+        got = f.permute(0, 4, 1, 2, 3)
+        assert _rel(got, ref) < 1e-3, f"feature {i}"
+        loss = loss + (got * det_tensor(f"enc_r{i}_" + tag, ref.shape).to(DEV)).sum()
+    loss.backward()
+    assert _rel(m.layers[0].blocks[1].attn.qkv.weight.grad, g["d_qkv_w"]) < 5e-3
+    assert _rel(m.layers[0].blocks[1].attn.relative_position_bias_table.grad, g["d_table"]) < 5e-3
+    assert _rel(m.layers[1].downsample.reduction.weight.grad[:8], g["d_merge_w"]) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swin_unetr_vs_oracle(dtype):
+    """whole Swin-UNETR (reference-wired encoder + UNETR decoder) forward + DiceCE + backward vs the CPU oracle"""
+    from medicalsemseg_amd.losses import DiceCELoss
+    from medicalsemseg_amd.models import swin_unetr as P
+    from oracle import swin as O
+    from oracle.losses import dice_ce_loss
+    torch.manual_seed(0)
+    vol, hs = (32, 32, 32), 16
+    kw = dict(patch_size=(2, 2, 2), in_chans=1, embed_dim=hs, depths=(2, 2), num_heads=(1, 2), window_size=(4, 4))
+    ref = O.SwinUNETRCustom(O.SwinTransformerNNFormer(vol, **kw), 1, 3, hs, 2)
+    enc = P.SwinTransformerNNFormer(vol, drop_path_rate=0.0, compute_dtype=dtype, **kw)
+    net = P.SwinUNETRCustom(enc, 1, 3, vol, hs, (2, 2, 2), compute_dtype=dtype)
+    sd = {k: v for k, v in ref.state_dict().items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    x = det_tensor("su_x", (2, 1) + vol)
+    gl = torch.Generator().manual_seed(3)
+    y = torch.randint(0, 3, (2, 1) + vol, generator=gl).float()
+    out_ref = ref((x, None, None))
+    loss_ref = dice_ce_loss(out_ref, y)
+    loss_ref.backward()
+    out = net((x.to(DEV), None, None))
+    loss = DiceCELoss()(out, y.to(DEV))
+    loss.backward()
+    if dtype == torch.float32:
+        np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=2e-4)
+        assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4
+    else:
+        assert _rel(out, out_ref.detach().numpy()) < 0.08
+        assert abs(float(loss.detach()) - float(loss_ref.detach())) < 3e-2
+    pr = dict(ref.named_parameters())
+    num = den = 0.0
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        gr = pr[name].grad
+        num += float(((p.grad.cpu() - gr) ** 2).sum())
+        den += float((gr ** 2).sum())
+    tot = (num / den) ** 0.5
+    assert tot < (2e-3 if dtype == torch.float32 else 0.15), f"whole-net grad rel L2 err {tot:.3e}"
