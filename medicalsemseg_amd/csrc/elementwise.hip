@@ -145,11 +145,13 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
     if (r1 > S) r1 = S;
     const T* xn = x + (long long)n * S * ldx;
     float* wsb = ws + ((long long)n * gridDim.x + blockIdx.x) * C * nacc;
-    for (int gg = g; gg * W < C; gg += groups) {
+    for (int gbase = 0; gbase * W < C; gbase += groups) {   // uniform trip count: barriers inside
+        const int gg = gbase + g;
+        const bool act = gg * W < C;
         float s[W], s2[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) s[e] = s2[e] = 0.f;
-        if (rl < rows_par) {
+        if (act && rl < rows_par) {
 #pragma unroll 8
             for (long long r = r0 + rl; r < r1; r += rows_par) {
                 if constexpr (VEC) {
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
             red[(threadIdx.x * W + e) * 2 + 1] = s2[e];
         }
         __syncthreads();
-        if (rl == 0) {
+        if (act && rl == 0) {
 #pragma unroll
             for (int e = 0; e < W; ++e) {
                 float a = 0.f, b = 0.f;
@@ -205,7 +207,6 @@ int launch_stats(const void* x, long long ldx, float* out, int N, long long S, i
                  void* scratch, hipStream_t st) {
     const bool vec = vec_ok(x, ldx, C, sizeof(T));
     const RowMap m = row_map(C, vec ? DT<T>::EPC : 1);
-    if (ceil_div(C, vec ? DT<T>::EPC : 1) > 256) MSSEG_FAIL(MSSEG_EINVAL, "channel reduction: too many channels (%d)", C);
     long long blocks = reduce_blocks(S, m.rows_par, N, C, nacc);
     const long long rpb = ceil_div_ll(S, blocks);
     blocks = ceil_div_ll(S, rpb);
@@ -268,11 +269,13 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
     T* drn = (MODE == 2 && p.dres) ? (T*)p.dres + (long long)n * p.S * p.lddres : nullptr;
     const float invS = 1.0f / (float)p.S;
 
-    for (int gg = g; gg * W < p.C; gg += p.groups) {
+    for (int gbase = 0; gbase * W < p.C; gbase += p.groups) {   // uniform trip count: barriers inside
+        const int gg = gbase + g;
+        const bool act = gg * W < p.C;
         float mean[W], rstd[W], sc[W], sh[W], k0[W], k1[W], a0[W], a1[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-            const int c = gg * W + e;
+            const int c = act ? gg * W + e : 0;
             mean_rstd(p.stats, n, p.C, c, p.S, p.eps, mean[e], rstd[e]);
             const float ga = p.gamma ? p.gamma[c] : 1.f;
             sc[e] = rstd[e] * ga;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
                 k1[e] = p.red[((long long)n * p.C + c) * 2 + 1] * invS;
             }
         }
-        if (rl < p.rows_par) {
+        if (act && rl < p.rows_par) {
 #pragma unroll 4
             for (long long r = r0 + rl; r < r1; r += p.rows_par) {
                 float xv[W], o[W], yv[W], dv[W];
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
                 red[(threadIdx.x * W + e) * 2 + 1] = a1[e];
             }
             __syncthreads();
-            if (rl == 0) {
+            if (act && rl == 0) {
 #pragma unroll
                 for (int e = 0; e < W; ++e) {
                     float a = 0.f, b = 0.f;
@@ -394,7 +397,6 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
 
 template <typename T, int MODE> int launch_norm(NormParams& p, int N, bool vec, hipStream_t st) {
     const RowMap m = row_map(p.C, vec ? DT<T>::EPC : 1);
-    if (ceil_div(p.C, vec ? DT<T>::EPC : 1) > 256) MSSEG_FAIL(MSSEG_EINVAL, "instnorm: too many channels (%d)", p.C);
     p.groups = m.groups; p.rows_par = m.rows_par;
     long long blocks = reduce_blocks(p.S, m.rows_par, N, p.C, 2);
     p.rows_per_block = ceil_div_ll(p.S, blocks);

@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Training driver with the reference's flow and flags (``/root/reference/run_training.py:27-190``): distributed
+init -> seeds -> data -> build_model -> AdamW(+timm-style weight-decay groups) -> cosine schedule with linear warm-up
+-> resume -> DiceCE -> epochs of train_one_epoch / run_validation with best-mDice and periodic checkpoints.
+
+Differences: runs on MI355X through ``medicalsemseg_amd`` (no CPU fallback); ``--synthetic`` replaces the MONAI
+data pipeline (out of the hot-path scope); logging is stdout + ``log.txt`` JSON lines (tensorboardX / Neptune are not
+available here); bf16 compute instead of fp16 autocast, so the GradScaler is a disabled pass-through;
+gradients are exchanged with one flat RCCL all-reduce instead of DDP buckets.
+"""
+from __future__ import annotations
+
+import datetime
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from medicalsemseg_amd import parallel
+from medicalsemseg_amd.data import SyntheticLoader
+from medicalsemseg_amd.engine.train import train_one_epoch
+from medicalsemseg_amd.engine.val import run_validation
+from medicalsemseg_amd.losses import DiceCELoss
+from medicalsemseg_amd.models.model_builder import build_model
+from medicalsemseg_amd.optim import FlatAdamW, LinearWarmupCosineAnnealingLR, add_weight_decay
+from medicalsemseg_amd.utils import misc
+from medicalsemseg_amd.utils.arguments import get_args
+
+
+def main(cfg):
+    misc.init_distributed_mode(cfg)
+    if not torch.cuda.is_available():
+        raise SystemExit("run_training.py needs an MI355X: medicalsemseg_amd has no CPU fallback "
+                         "(the CPU oracle under oracle/ is test infrastructure)")
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)
+    seed = cfg.seed + misc.get_rank()
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+
+    if not cfg.synthetic:
+        raise SystemExit("only --synthetic data is available in this build: the MONAI/Decathlon pipeline of the "
+                         "reference (data/*) is outside the hot-path scope (SURVEY.md section 2)")
+    vol = cfg.vol_size if isinstance(cfg.vol_size, int) else cfg.vol_size[0]
+    vval = cfg.synthetic_val_size if isinstance(cfg.synthetic_val_size, int) else cfg.synthetic_val_size[0]
+    loader_train = SyntheticLoader(cfg.synthetic_steps, cfg.n_images_per_batch, vol, cfg.in_chans, cfg.output_dim, seed)
+    loader_val = SyntheticLoader(1, 1, vval, cfg.in_chans, cfg.output_dim, seed + 7, with_crop_info=False)
+
+    model = build_model(cfg).to(device)
+    print("parameters:", misc.count_parameters(model))
+    groups = add_weight_decay(model, cfg.weight_decay)
+    optimizer = FlatAdamW(groups, lr=cfg.lr, betas=(0.9, 0.95), eps=1e-6)
+    if cfg.distributed:
+        ws = parallel.world_size()
+
+        def sync_gradients():
+            parallel.all_reduce_flat_grads(optimizer.flat_grad)
+            optimizer._gscale.mul_(1.0 / ws)
+        optimizer.sync_gradients = sync_gradients
+        # identical initial weights on every rank
+        torch.distributed.broadcast(optimizer.flat_param, src=0)
+    loss_scaler = torch.amp.GradScaler("cuda", enabled=False)
+    scheduler = LinearWarmupCosineAnnealingLR(optimizer, warmup_epochs=cfg.warmup_epochs, max_epochs=cfg.epochs)
+    misc.load_model(cfg, model, optimizer, loss_scaler, scheduler)
+    if cfg.loss_fn != "DiceCE":
+        raise RuntimeError("Could not parse loss function argument (only DiceCE is on the hot path).")
+    criterion = DiceCELoss(to_onehot_y=True, softmax=True, squared_pred=True, smooth_nr=cfg.smooth_nr, smooth_dr=cfg.smooth_dr)
+
+    best, best_epoch = 0.0, 0
+    start = time.time()
+    for epoch in range(cfg.start_epoch, cfg.epochs):
+        if cfg.distributed:
+            torch.distributed.barrier()
+        stats = train_one_epoch(model, loader_train, optimizer, criterion, device, epoch, loss_scaler, cfg)
+        if (epoch + 1) % cfg.val_interval == 0 or epoch + 1 == cfg.epochs:
+            if cfg.distributed:
+                torch.distributed.barrier()
+            vstats = run_validation(model, loader_val, criterion, device, epoch, cfg)
+            stats.update(vstats)
+            if vstats["val/mDice"] > best and cfg.output_dir:
+                best, best_epoch = vstats["val/mDice"], epoch
+                misc.save_model(cfg, epoch, model, optimizer, loss_scaler, scheduler, filename="best_model.pth")
+        if cfg.output_dir and ((epoch + 1) % cfg.save_ckpt_freq == 0 or epoch + 1 == cfg.epochs):
+            misc.save_model(cfg, epoch, model, optimizer, loss_scaler, scheduler)
+        if cfg.output_dir and misc.is_main_process():
+            os.makedirs(cfg.output_dir, exist_ok=True)
+            with open(os.path.join(cfg.output_dir, "log.txt"), "a") as f:
+                f.write(json.dumps({"epoch": epoch, **{k: float(v) for k, v in stats.items()}}) + "\n")
+        scheduler.step()
+    print("Training time", str(datetime.timedelta(seconds=int(time.time() - start))), "best val mDice", best, "at", best_epoch)
+    if parallel.is_dist():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(get_args())

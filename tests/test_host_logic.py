@@ -1,0 +1,183 @@
+"""CPU tests of the host logic that surrounds the kernels: CLI, LR schedule, meters, sliding-window geometry, the
+engine loop (driven with the CPU oracle injected as model / criterion), and the N>1 paths on gloo (world_size 2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_arguments_defaults_and_list_collapsing():
+    from medicalsemseg_amd.utils.arguments import get_args
+    a = get_args([])
+    assert a.model == "UNETR_Official" and a.vol_size == 96 and a.patch_size == 16 and a.window_size == 6
+    assert a.depths == (2, 2, 2, 2) and a.num_heads == (3, 6, 12, 24) and a.lr == 4e-4 and a.seed == 13
+    assert a.pin_mem is True and a.neptune_logging is True and a.gradient_clipping is None and a.backend == "nccl"
+    b = get_args("--model UNet --vol_size 64 64 32 --window_size 6 6 6 3 --no_pin_memory --qkv_bias --output_dim 2".split())
+    assert b.vol_size == (64, 64, 32) and b.window_size == (6, 6, 6, 3) and b.pin_mem is False and b.qkv_bias
+
+
+def test_lr_schedule_matches_reference_trace(golden_dir):
+    from medicalsemseg_amd.optim import LinearWarmupCosineAnnealingLR
+    g = np.load(os.path.join(golden_dir, "lr_misc.npz"))
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=4e-4)
+    sch = LinearWarmupCosineAnnealingLR(opt, warmup_epochs=40, max_epochs=200)
+    lrs = []
+    for _ in range(200):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    np.testing.assert_allclose(np.array(lrs), g["lrs"], rtol=1e-9, atol=1e-15)
+
+
+def test_misc_helpers_match_reference(golden_dir):
+    from medicalsemseg_amd.utils import misc
+    g = np.load(os.path.join(golden_dir, "lr_misc.npz"))
+    np.testing.assert_array_equal(misc.get_affine_xyz(torch.from_numpy(g["aff_in"])).numpy(), g["aff_xyz"])
+    t = {"orig_size": [torch.tensor([100., 120.]), torch.tensor([110., 90.]), torch.tensor([64., 80.])],
+         "extra_info": {"center": [torch.tensor([10., 30.]), torch.tensor([55., 45.]), torch.tensor([32., 8.])]}}
+    np.testing.assert_allclose(misc.get_rel_crop_loc(t).numpy(), g["rel_crop"])
+    m = misc.SmoothedValue(window_size=3)
+    for v in (1.0, 2.0, 3.0, 4.0):
+        m.update(v)
+    assert m.global_avg == 2.5 and m.value == 4.0 and m.max == 4.0 and abs(m.avg - 3.0) < 1e-6
+
+
+def test_sliding_window_geometry_matches_oracle_and_known_answers():
+    from medicalsemseg_amd.engine import utils as P
+    from oracle import sliding_window as O
+    starts = P.window_starts((512,) * 3, (96,) * 3, P.get_scan_interval((512,) * 3, (96,) * 3, 3, 0.5))
+    assert len(starts) == 1000 and starts[-1] == (416, 416, 416) and starts[1] == (0, 0, 48)
+    for img, roi, ov in [((100, 70, 96), (96, 64, 96), 0.5), ((130, 130, 130), (64, 64, 64), 0.25), ((96,) * 3, (96,) * 3, 0.5)]:
+        iv = P.get_scan_interval(img, roi, 3, ov)
+        assert iv == O.get_scan_interval(img, roi, 3, ov)
+        assert [tuple(s.start for s in sl) for sl in O.dense_patch_slices(img, roi, iv)] == P.window_starts(img, roi, iv)
+    imp = P.importance_map((96, 96, 96), "gaussian", 0.125)
+    assert torch.equal(imp, O.compute_importance_map((96, 96, 96), "gaussian", 0.125))
+    assert imp.max() == 1.0 and imp[48, 48, 48] == 1.0 and imp.min() > 0
+    assert torch.allclose(imp[1:], imp[1:].flip(0)) and torch.allclose(imp[:, 1:], imp[:, 1:].flip(1))
+    assert torch.equal(P.importance_map((8, 8, 8), "constant"), torch.ones(8, 8, 8))
+
+
+def test_oracle_known_answers_dice_ce():
+    from oracle.losses import dice_ce_loss, dice_metric
+    K, V = 3, 4 * 4 * 4
+    labels = torch.zeros(1, 1, 4, 4, 4)
+    labels[0, 0, :2] = 1
+    labels[0, 0, 3] = 2
+    counts = [float((labels == c).sum()) for c in range(K)]
+    loss = dice_ce_loss(torch.zeros(1, K, 4, 4, 4), labels, 1e-5, 1e-5)
+    dice = np.mean([1 - (2 * vc / K + 1e-5) / (V / K ** 2 + vc + 1e-5) for vc in counts])
+    assert abs(float(loss) - (dice + np.log(K))) < 1e-6
+    onehot = torch.nn.functional.one_hot(labels.long().squeeze(1), K).movedim(-1, 1).float()
+    s, nn_ = dice_metric(onehot * 10, labels)
+    assert torch.allclose(s, torch.ones(1, K)) and nn_.sum() == K
+    s2, _ = dice_metric(onehot.roll(1, 1) * 10, labels)
+    assert torch.all(s2 == 0)
+    s3, nn3 = dice_metric(onehot * 10, torch.zeros_like(labels))
+    assert torch.isnan(s3[0, 1]) and nn3[0, 1] == 0
+
+
+class _OracleCriterion(torch.nn.Module):
+    """CPU oracle injected into the product engine loop (tests only)."""
+
+    def forward(self, logits, labels):
+        from oracle.losses import dice_ce_loss
+        return dice_ce_loss(logits, labels)
+
+    def hard_dice(self, logits, labels):
+        from oracle.losses import dice_metric
+        return dice_metric(logits, labels)
+
+
+def test_engine_train_loop_with_oracle_model_on_cpu():
+    """config 1 plumbing: UNet-small, 64^3... (here 32^3 to stay fast), batch 2, CPU: the engine loop, meters,
+    optimizer step and metric bookkeeping run end to end and the loss goes down."""
+    from medicalsemseg_amd.data import SyntheticLoader
+    from medicalsemseg_amd.engine.train import train_one_epoch
+    from medicalsemseg_amd.optim import add_weight_decay
+    from medicalsemseg_amd.utils.arguments import get_args
+    from oracle.blocks import UNET_FEATURES, BasicUNet
+    cfg = get_args("--model UNetSmall --output_dim 2 --vol_size 32".split())
+    torch.manual_seed(0)
+    model = BasicUNet(1, 2, UNET_FEATURES["UNetSmall"])
+    opt = torch.optim.AdamW(add_weight_decay(model, 1e-5), lr=2e-3, betas=(0.9, 0.95), eps=1e-6)
+    loader = SyntheticLoader(4, 2, 32, 1, 2, seed=1)
+    scaler = torch.amp.GradScaler("cpu", enabled=False)
+    s0 = train_one_epoch(model, loader, opt, _OracleCriterion(), torch.device("cpu"), 0, scaler, cfg)
+    s1 = train_one_epoch(model, loader, opt, _OracleCriterion(), torch.device("cpu"), 1, scaler, cfg)
+    assert set(s0) == {"train/lr", "train/loss", "train/mDice", "train/class0Dice", "train/class1Dice"}
+    assert s1["train/loss"] < s0["train/loss"] and 0 <= s1["train/mDice"] <= 1
+
+
+def test_build_model_surface():
+    from medicalsemseg_amd.models.model_builder import build_model
+    from medicalsemseg_amd.utils.arguments import get_args
+    m = build_model(get_args("--model UNet --output_dim 3".split()))
+    assert sum(p.numel() for p in m.parameters()) == 5749443
+    sw = build_model(get_args("--model nnFormerUNETR --patch_size 2 --window_size 6 6 6 3 --qkv_bias --output_dim 3".split()))
+    n_enc = sum(p.numel() for p in sw.encoder.parameters())
+    assert n_enc == 15362430, n_enc   # the reference encoder's parameter count
+    with pytest.raises(NotImplementedError):
+        build_model(get_args("--model SwInception".split()))
+    with pytest.raises(ValueError):
+        build_model(get_args([]))   # the reference's default 'UNETR_Official' matches no branch either
+
+
+def test_swin_unetr_state_dict_matches_oracle_layout():
+    from medicalsemseg_amd.models import swin_unetr as P
+    from oracle import swin as O
+    kw = dict(patch_size=(2, 2, 2), in_chans=1, embed_dim=16, depths=(2, 2), num_heads=(1, 2), window_size=(4, 4))
+    ref = O.SwinUNETRCustom(O.SwinTransformerNNFormer((32,) * 3, **kw), 1, 3, 16, 2)
+    net = P.SwinUNETRCustom(P.SwinTransformerNNFormer((32,) * 3, **kw), 1, 3, (32,) * 3, 16, (2, 2, 2))
+    a, b = net.state_dict(), ref.state_dict()
+    assert sorted(a) == sorted(b) and all(a[k].shape == b[k].shape for k in a)
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from medicalsemseg_amd import parallel
+    from medicalsemseg_amd.utils import misc
+    parallel.init_from_env("gloo")
+    flat = torch.full((1000,), float(rank + 1))
+    parallel.all_reduce_flat_grads(flat)
+    lo, hi = parallel.shard_windows(1000)
+    m = misc.SmoothedValue()
+    m.update(float(rank + 1), n=rank + 1)
+    m.synchronize_between_processes()
+    q.put((rank, float(flat[0]), parallel.all_reduce_mean(float(rank)), (lo, hi), m.count, m.total))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world_size_2_flat_allreduce_and_window_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [3.0, 3.0]            # sum of 1 and 2
+    assert [r[2] for r in res] == [0.5, 0.5]            # mean of ranks
+    assert res[0][3] == (0, 500) and res[1][3] == (500, 1000)
+    assert all(r[4] == 3 and r[5] == 5.0 for r in res)  # meter: counts 1+2, totals 1*1 + 2*2
+
+
+def test_window_sharding_is_a_partition():
+    from medicalsemseg_amd.parallel import shard_windows
+    for n, ws in [(1000, 8), (27, 4), (5, 8), (64, 3)]:
+        spans = [shard_windows(n, ws, r) for r in range(ws)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
