@@ -201,7 +201,9 @@ int msseg_dice_ce_bwd(const void* logits, long long ld, int dtype, const void* l
  * ------------------------------------------------------------------------------------------- */
 int msseg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
                      long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                     const float* grad_scale, msseg_stream_t stream);
+                     const float* grad_scale, const float* dev_hyper /* nullable: device [lr, step] overriding the
+                     host values, so a captured hipGraph can be replayed while the schedule advances */,
+                     msseg_stream_t stream);
 /* out[0] = sum of squares of x[0..n) (caller zero-fills out). */
 int msseg_sumsq(const float* x, long long n, float* out, msseg_stream_t stream);
 

@@ -572,8 +572,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, const uint8_t* __restrict__ decay, long long n, float lr, float b1,
-                             float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* gscale) {
+                             float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* gscale,
+                             const float* hyper) {
     const float gs = gscale ? gscale[0] : 1.f;
+    if (hyper) {  // device-resident (lr, step): lets a captured hipGraph replay with a changing schedule
+        lr = hyper[0];
+        const float st = hyper[1];
+        bc1 = 1.f - powf(b1, st);
+        bc2_sqrt = sqrtf(1.f - powf(b2, st));
+    }
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float gi = g[i] * gs;
         float pi = p[i];
@@ -806,12 +813,13 @@ int msseg_add(const void* a, long long lda, const void* b, long long ldb, void* 
 
 int msseg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
                      long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                     const float* grad_scale, msseg_stream_t stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) MSSEG_FAIL(MSSEG_EINVAL, "adamw_step: bad args");
+                     const float* grad_scale, const float* dev_hyper, msseg_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || (step < 1 && !dev_hyper))
+        MSSEG_FAIL(MSSEG_EINVAL, "adamw_step: bad args");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, decay_mask, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                       exp_avg_sq, decay_mask, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, dev_hyper);
     MSSEG_CHECK_LAUNCH("adamw_step");
     return MSSEG_OK;
 }

@@ -264,19 +264,30 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
                 for (int j = 0; j < NT; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
         // ---------------- MFMA ----------------
+        // Operand fragments are double-buffered in registers: the 6 LDS reads of tap t+1 are issued before the
+        // MFMAs of tap t, so the matrix pipe runs under one full LDS latency instead of waiting for it per pair.
+        {
+            u32x4_t af[2][MT], bf[2][NT];
+            auto load_frags = [&](int tap, int buf) {
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                const int toff = (NTAPS == 27) ? ((kd * PH + kh) * PW + kw) * 16 : 0;
 #pragma unroll
-        for (int tap = 0; tap < NTAPS; ++tap) {
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const int toff = (NTAPS == 27) ? ((kd * PH + kh) * PW + kw) * 16 : 0;
-            u32x4_t bf[NT];
+                for (int j = 0; j < NT; ++j)
+                    bf[buf][j] = *(const u32x4_t*)(ldsB + bbase + tap * (4 * COUTB * 16) + j * 256);
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                bf[j] = *(const u32x4_t*)(ldsB + bbase + tap * (4 * COUTB * 16) + j * 256);
+                for (int m = 0; m < MT; ++m) af[buf][m] = *(const u32x4_t*)(ldsA + abase[m] + toff);
+            };
+            load_frags(0, 0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const u32x4_t af = *(const u32x4_t*)(ldsA + abase[m] + toff);
+            for (int tap = 0; tap < NTAPS; ++tap) {
+                const int cur = tap & 1;
+                if (tap + 1 < NTAPS) load_frags(tap + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) mma_chunk<T>(acc[m][j], bf[j], af);
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) mma_chunk<T>(acc[m][j], bf[cur][j], af[cur][m]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (kb == p.NKB - 1) {

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
             if constexpr (sizeof(T) == 2) {
                 // lane = 16*g + 4*qr + pc : group g covers voxels ks*32 + 8g + {0..7}; this lane supplies the
                 // address of block row qr (voxel) and the 4 channels 4*pc.. of the 16-channel tile.
+                // Fragments are double-buffered: the transposing reads of tap t+1 are in flight under tap t's MFMAs.
                 const int g = lane >> 4, qr = (lane >> 2) & 3, pc = lane & 3;
                 int prow[2], qrow[2];
 #pragma unroll
@@ -212,32 +213,45 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
                     prow[i] = tv * RS + pc * 8;
                     qrow[i] = ((td * PH + th) * PW + tw) * RS + pc * 8;
                 }
-                u32x4_t pf[CT];
-#pragma unroll
-                for (int a = 0; a < CT; ++a) {
-                    bf16x4_t lo = lds_tr_read(ldsP + prow[0] + a * 32);
-                    bf16x4_t hi = lds_tr_read(ldsP + prow[1] + a * 32);
+                auto tr_frag = [&](const unsigned char* base, int r0, int r1) -> u32x4_t {
+                    bf16x4_t lo = lds_tr_read(base + r0);
+                    bf16x4_t hi = lds_tr_read(base + r1);
                     bf16x8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    pf[a] = __builtin_bit_cast(u32x4_t, f);
+                    return __builtin_bit_cast(u32x4_t, f);
+                };
+                auto tap_off = [&](int tap) -> int {
+                    if constexpr (NTAPS == 27) {
+                        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                        return ((kd * PH + kh) * PW + kw) * RS;
+                    } else {
+                        return 0;
+                    }
+                };
+                u32x4_t pf[CT], qf[2][CT];
+#pragma unroll
+                for (int a = 0; a < CT; ++a) pf[a] = tr_frag(ldsP, prow[0] + a * 32, prow[1] + a * 32);
+                {
+                    const int toff = tap_off(tap0);
+#pragma unroll
+                    for (int b = 0; b < CT; ++b) qf[0][b] = tr_frag(ldsQ, qrow[0] + toff + b * 32, qrow[1] + toff + b * 32);
                 }
 #pragma unroll
                 for (int tt = 0; tt < TAPW; ++tt) {
                     const int tap = tap0 + tt;
                     if (tap >= NTAPS) break;
-                    int toff = 0;
-                    if constexpr (NTAPS == 27) {
-                        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                        toff = ((kd * PH + kh) * PW + kw) * RS;
-                    }
+                    const int cur = tt & 1;
+                    if (tt + 1 < TAPW && tap + 1 < NTAPS) {
+                        const int toff = tap_off(tap + 1);
 #pragma unroll
-                    for (int b = 0; b < CT; ++b) {
-                        bf16x4_t lo = lds_tr_read(ldsQ + qrow[0] + toff + b * 32);
-                        bf16x4_t hi = lds_tr_read(ldsQ + qrow[1] + toff + b * 32);
-                        bf16x8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        const u32x4_t qf = __builtin_bit_cast(u32x4_t, f);
-#pragma unroll
-                        for (int a = 0; a < CT; ++a) mma_chunk<bf16_t>(acc[tt][a][b], pf[a], qf);
+                        for (int b = 0; b < CT; ++b)
+                            qf[cur ^ 1][b] = tr_frag(ldsQ, qrow[0] + toff + b * 32, qrow[1] + toff + b * 32);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < CT; ++b)
+#pragma unroll
+                        for (int a = 0; a < CT; ++a) mma_chunk<bf16_t>(acc[tt][a][b], pf[a], qf[cur][b]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 const int r = lane & 15, q = lane >> 4;

@@ -62,7 +62,7 @@ SIGNATURES = {
     "msseg_dice_ce_partials": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _i, _ll, _i, _vp], _i),
     "msseg_dice_ce_finalize": ([_vp, _vp, _i, _ll, _i, _f, _f, _vp], _i),
     "msseg_dice_ce_bwd": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, _ll, _i, _f, _f, _vp], _i),
-    "msseg_adamw_step": ([_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _vp], _i),
+    "msseg_adamw_step": ([_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp], _i),
     "msseg_sumsq": ([_vp, _ll, _vp, _vp], _i),
     "msseg_sw_blend": ([_vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_sw_normalize": ([_vp, _vp, _i, _ll, _vp], _i),
@@ -492,10 +492,11 @@ def dice_ce_bwd(logits, labels, partial, gscale, dlogits, n_cls, smooth_nr, smoo
 # optimiser
 # --------------------------------------------------------------------------------------------
 def adamw_step(param, grad, exp_avg, exp_avg_sq, decay_mask, lr, beta1, beta2, eps, weight_decay, step,
-               grad_scale=None):
+               grad_scale=None, dev_hyper=None):
     _need_gpu(param, grad, exp_avg, exp_avg_sq)
     _ck(lib().msseg_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(decay_mask), param.numel(), lr,
-                               beta1, beta2, eps, weight_decay, step, _p(grad_scale), _stream()), "adamw_step")
+                               beta1, beta2, eps, weight_decay, step, _p(grad_scale), _p(dev_hyper), _stream()),
+        "adamw_step")
 
 
 def sumsq(x, out):

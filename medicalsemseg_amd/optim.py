@@ -70,6 +70,9 @@ class FlatAdamW(torch.optim.Optimizer):
         self._step = 0
         self._gscale = torch.ones(1, dtype=torch.float32, device=dev)
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        # device-resident (lr, step): the fused kernel reads them, so a captured hipGraph replays correctly
+        self._hyper = torch.tensor([lr, 0.0], dtype=torch.float32, device=dev)
+        self._lr_on_device = lr
         self.attach_grads()
 
     def attach_grads(self):
@@ -96,15 +99,24 @@ class FlatAdamW(torch.optim.Optimizer):
         self._gscale.copy_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
         return total
 
+    def sync_lr(self):
+        """push the host learning rate to the device copy (call between graph replays when the schedule moves)."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_on_device:
+            self._hyper[0:1].fill_(lr)
+            self._lr_on_device = lr
+
     @torch.no_grad()
     def step(self, closure=None):
         self.attach_grads()
         self._step += 1
+        self.sync_lr()
         lr = self.param_groups[0]["lr"]
         b1, b2 = self.param_groups[0]["betas"]
         eps = self.param_groups[0]["eps"]
+        self._hyper[1:2].add_(1.0)
         hip.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.decay_mask, lr, b1, b2, eps,
-                       self._wd, self._step, self._gscale)
+                       self._wd, self._step, self._gscale, self._hyper)
         self._gscale.fill_(1.0)
         layers.bump_weights_epoch()
         return None

@@ -366,3 +366,31 @@ def test_conv3d_k3_fused_stats(dtype, cin, cout, sp, N):
     s2 = torch.empty_like(stats)
     hip.conv3d_k3(xg, wp, b.to(dev), y, cin, cout, s2)
     assert torch.equal(s2, stats)
+
+
+def test_flat_adamw_matches_torch_adamw():
+    """fused flat-buffer AdamW (+ weight-decay grouping, + folded gradient clipping) vs torch.optim.AdamW"""
+    from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay
+    dev = _dev()
+    torch.manual_seed(0)
+    mk = lambda: torch.nn.Sequential(torch.nn.Conv3d(2, 4, 3), torch.nn.InstanceNorm3d(4, affine=True), torch.nn.Conv3d(4, 3, 1))
+    a, b = mk().to(dev), mk().to(dev)
+    b.load_state_dict(a.state_dict())
+    oa = FlatAdamW(add_weight_decay(a, 0.05), lr=1e-2, betas=(0.9, 0.95), eps=1e-6)
+    ob = torch.optim.AdamW(add_weight_decay(b, 0.05), lr=1e-2, betas=(0.9, 0.95), eps=1e-6)
+    for it in range(5):
+        gs = [torch.randn_like(p) * (3.0 if it == 2 else 0.1) for p in a.parameters()]
+        for p, g in zip(a.parameters(), gs):
+            p.grad.copy_(g)
+        for p, g in zip(b.parameters(), gs):
+            p.grad = g.clone()
+        na = oa.clip_grad_norm_(1.0)
+        nb = torch.nn.utils.clip_grad_norm_(b.parameters(), 1.0)
+        assert abs(float(na) - float(nb)) < 1e-4 * float(nb)
+        if it == 3:
+            for g_ in oa.param_groups + ob.param_groups:
+                g_["lr"] = 5e-3
+        oa.step(); ob.step()
+        oa.zero_grad(); ob.zero_grad()
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert float((p - q).abs().max()) < 2e-6, n
