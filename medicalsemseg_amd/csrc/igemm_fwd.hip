@@ -39,6 +39,7 @@ struct IgemmParams {
     int cin, k, s, p;    // gather: real Cin, kernel, stride, pad
     int creal;           // deconv modes: real channel count of the fine tensor
     int vec_store;       // y / ldy allow 4-element vector stores
+    int rel32_ok;        // halo-relative element offsets fit 32 bits (precomputed-offset staging path)
     float* stats;        // optional fused per-(n, cout) (sum, sum of squares) of the stored output
     float* stats_ws;     // scratch partials
     unsigned int* counter;
@@ -205,11 +206,57 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
         return val;
     };
     u32x4_t pa[NIT_A], pb[NIT_B];
-    auto fetch = [&](const TileCo& tc, int kb, bool with_b) {
+    // DIRECT source: the (halo voxel, chunk) a thread stages is the same for every tile, so its element offset
+    // relative to the tile origin and its halo coordinates are computed once (VALU work per tile drops from ~40 to
+    // ~3 instructions per chunk; interior tiles skip the bounds checks altogether).
+    int a_rel[NIT_A], a_pk[NIT_A];
+    const int XD = STRIDE == 1 ? p.D : p.ID, XH = STRIDE == 1 ? p.H : p.IH, XW = STRIDE == 1 ? p.W : p.IW;
+    if constexpr (SRC == SRC_DIRECT) {
 #pragma unroll
         for (int it = 0; it < NIT_A; ++it) {
             const int i = tid + it * NTHREADS;
-            pa[it] = (i < HV * 4) ? load_a_chunk(tc, kb, i) : u32x4_t{0u, 0u, 0u, 0u};
+            const int cq = i & 3, hv = i >> 2;
+            const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
+            a_rel[it] = (int)((((long long)hd * XH + hh) * XW + hw) * p.ldx) + cq * EPC;
+            a_pk[it] = (i < HV * 4) ? (hd | (hh << 8) | (hw << 16)) : -1;
+        }
+    }
+    auto fetch = [&](const TileCo& tc, int kb, bool with_b) {
+        if constexpr (SRC == SRC_DIRECT) {
+            if (p.rel32_ok) {
+                const int dB = tc.d0 * STRIDE - PAD, hB = tc.h0 * STRIDE - PAD, wB = tc.w0 * STRIDE - PAD;
+                const long long basev = (((long long)tc.n * XD + dB) * XH + hB) * XW + wB;
+                const T* bp = xg + basev * p.ldx + kb * CB;
+                const bool interior = dB >= 0 && dB + C::PD <= XD && hB >= 0 && hB + PH <= XH && wB >= 0 && wB + PW <= XW;
+                const int nchunk = (p.K - kb * CB + EPC - 1) / EPC;   // valid 16-byte chunks of this channel block
+                const bool cok = (tid & 3) < nchunk;
+                if (interior) {
+#pragma unroll
+                    for (int it = 0; it < NIT_A; ++it)
+                        pa[it] = (cok && a_pk[it] >= 0) ? *(const u32x4_t*)(bp + a_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
+                } else {
+#pragma unroll
+                    for (int it = 0; it < NIT_A; ++it) {
+                        const int pk = a_pk[it];
+                        const int d = dB + (pk & 255), h = hB + ((pk >> 8) & 255), w = wB + ((pk >> 16) & 255);
+                        const bool ok = cok && pk >= 0 && (unsigned)d < (unsigned)XD && (unsigned)h < (unsigned)XH &&
+                                        (unsigned)w < (unsigned)XW;
+                        pa[it] = ok ? *(const u32x4_t*)(bp + a_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIT_A; ++it) {
+                    const int i = tid + it * NTHREADS;
+                    pa[it] = (i < HV * 4) ? load_a_chunk(tc, kb, i) : u32x4_t{0u, 0u, 0u, 0u};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT_A; ++it) {
+                const int i = tid + it * NTHREADS;
+                pa[it] = (i < HV * 4) ? load_a_chunk(tc, kb, i) : u32x4_t{0u, 0u, 0u, 0u};
+            }
         }
         if (with_b) {
             const u32x4_t* src = (const u32x4_t*)((const unsigned char*)p.wp + ((long long)coutblk * p.NKB + kb) * C::B_BYTES);
@@ -402,6 +449,10 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
     p.ntiles = (int)nt;
     p.NKB = ceil_div(p.K, C::CB);
     p.vec_store = ((((uintptr_t)p.y) % (4 * sizeof(T))) == 0 && (p.ldy % 4) == 0) ? 1 : 0;
+    {
+        const long long xh = STRIDE == 1 ? p.H : p.IH, xw = STRIDE == 1 ? p.W : p.IW;
+        p.rel32_ok = ((long long)(C::PD + 1) * xh * xw * p.ldx < 0x7fffffffLL) ? 1 : 0;
+    }
     auto kern = igemm_fwd_kernel<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE>;
     static bool attr_set = false;
     if (!attr_set) {

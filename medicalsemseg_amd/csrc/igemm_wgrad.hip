@@ -29,6 +29,7 @@ struct WgradParams {
     int tiles_d, tiles_h, tiles_w, ntiles;
     int cin, k, s, p;
     int creal;
+    int rel32_ok;      // tile-relative element offsets of P and Q fit 32 bits
 };
 
 template <typename T, int NTAPS, int TD, int TH, int TW> struct WgCfg {
@@ -165,7 +166,63 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
         return val;
     };
     u32x4_t pp[NIT_P], pq[NIT_Q];
+    // tile-invariant per-thread staging offsets (element offset relative to the tile origin + packed coordinates):
+    // interior tiles then need one add per chunk instead of ~40 VALU instructions
+    int p_rel[NIT_P], p_pk[NIT_P], q_rel[NIT_Q], q_pk[NIT_Q];
+    const bool fast = (QSRC == Q_DIRECT) && p.rel32_ok && (p.M % EPC == 0);
+    if (fast) {
+#pragma unroll
+        for (int it = 0; it < NIT_P; ++it) {
+            const int i = tid + it * 256;
+            const int tv = i >> 2;
+            const int td = tv / (TH * TW), th = (tv / TW) % TH, tw = tv % TW;
+            p_rel[it] = (int)((((long long)td * p.H + th) * p.W + tw) * p.ldp) + (i & 3) * EPC;
+            p_pk[it] = (i < TV * 4) ? (td | (th << 8) | (tw << 16)) : -1;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT_Q; ++it) {
+            const int i = tid + it * 256;
+            const int hv = i >> 2;
+            const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
+            q_rel[it] = (int)((((long long)hd * p.H + hh) * p.W + hw) * p.ldq) + (i & 3) * EPC;
+            q_pk[it] = (i < HV * 4) ? (hd | (hh << 8) | (hw << 16)) : -1;
+        }
+    }
     auto fetch = [&](const TileCo& tc) {
+        if (fast) {
+            const long long pbase = (((long long)tc.n * p.D + tc.d0) * p.H + tc.h0) * p.W + tc.w0;
+            const long long qbase = (((long long)tc.n * p.D + tc.d0 - PAD) * p.H + tc.h0 - PAD) * p.W + tc.w0 - PAD;
+            const T* pb = pg + pbase * p.ldp + mblk * CBW;
+            const T* qb = qg + qbase * p.ldq + kblk * CBW;
+            const bool pcok = mblk * CBW + (tid & 3) * EPC < p.M, qcok = kblk * CBW + (tid & 3) * EPC < p.K;
+            const bool interior = tc.d0 - PAD >= 0 && tc.d0 + TD + PAD <= p.D && tc.h0 - PAD >= 0 &&
+                                  tc.h0 + TH + PAD <= p.H && tc.w0 - PAD >= 0 && tc.w0 + TW + PAD <= p.W;
+            if (interior) {
+#pragma unroll
+                for (int it = 0; it < NIT_P; ++it)
+                    pp[it] = (pcok && p_pk[it] >= 0) ? *(const u32x4_t*)(pb + p_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int it = 0; it < NIT_Q; ++it)
+                    pq[it] = (qcok && q_pk[it] >= 0) ? *(const u32x4_t*)(qb + q_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIT_P; ++it) {
+                    const int pk = p_pk[it];
+                    const int d = tc.d0 + (pk & 255), h = tc.h0 + ((pk >> 8) & 255), w = tc.w0 + ((pk >> 16) & 255);
+                    const bool ok = pcok && pk >= 0 && d < p.D && h < p.H && w < p.W;
+                    pp[it] = ok ? *(const u32x4_t*)(pb + p_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int it = 0; it < NIT_Q; ++it) {
+                    const int pk = q_pk[it];
+                    const int d = tc.d0 - PAD + (pk & 255), h = tc.h0 - PAD + ((pk >> 8) & 255), w = tc.w0 - PAD + ((pk >> 16) & 255);
+                    const bool ok = qcok && pk >= 0 && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H &&
+                                    (unsigned)w < (unsigned)p.W;
+                    pq[it] = ok ? *(const u32x4_t*)(qb + q_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NIT_P; ++it) {
             const int i = tid + it * 256;
@@ -348,6 +405,10 @@ int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes
     p.ntiles = (int)nt;
     p.mblks = ceil_div(p.M, C::CBW);
     p.kblks = ceil_div(p.K, C::CBW);
+    {
+        const long long ldm = p.ldp > p.ldq ? p.ldp : p.ldq;
+        p.rel32_ok = ((long long)(C::PD + 1) * p.H * p.W * ldm < 0x7fffffffLL) ? 1 : 0;
+    }
     const int pairs = p.mblks * p.kblks;
     const int wave_slots = (NTAPS == 27) ? 1 : C::WAVES;
     const size_t slab_bytes = (size_t)C::SLAB_FLOATS * 4;
