@@ -394,6 +394,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceParams p)
     }
 }
 
+// few slabs (small-spatial, many-channel layers): one thread per output, no LDS
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const ReduceParams p) {
+    const long long total = (long long)p.M * p.T * p.K;
+    const long long slabf = (long long)p.T * p.cbw * p.cbw;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int k = (int)(i % p.K);
+        const int t = (int)((i / p.K) % p.T);
+        const int m = (int)(i / ((long long)p.K * p.T));
+        const int mb = m / p.cbw, ml = m % p.cbw, kb = k / p.cbw, kl = k % p.cbw;
+        const float* src = p.slabs + ((long long)(mb * p.kblks + kb) * p.nslots) * slabf + ((long long)t * p.cbw + ml) * p.cbw + kl;
+        float s = 0.f;
+#pragma unroll 8
+        for (int sl = 0; sl < p.nslots; ++sl) s += src[(long long)sl * slabf];
+        const long long di = (long long)(m / p.M0) * p.s_m1 + (long long)(m % p.M0) * p.s_m0 + (long long)t * p.s_t +
+                             (long long)(k / p.K0) * p.s_k1 + (long long)(k % p.K0) * p.s_k0;
+        p.dw[di] = p.accumulate ? p.dw[di] + s : s;
+    }
+}
+
 template <typename T, int NTAPS, int QSRC, int TD, int TH, int TW>
 int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes, hipStream_t stream) {
     using C = WgCfg<T, NTAPS, TD, TH, TW>;
@@ -433,9 +452,15 @@ int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes
     rp.slabs = p.slabs;
     rp.mblks = p.mblks; rp.kblks = p.kblks; rp.nslots = (int)gx * wave_slots; rp.cbw = C::CBW;
     const long long total = (long long)rp.M * rp.T * rp.K;
-    int rb = (int)((total + 31) / 32);
-    if (rb > 4096) rb = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, rp);
+    if (rp.nslots <= 32) {
+        int rb = (int)((total + 255) / 256);
+        if (rb > 8192) rb = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3(rb), dim3(256), 0, stream, rp);
+    } else {
+        int rb = (int)((total + 31) / 32);
+        if (rb > 4096) rb = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, rp);
+    }
     MSSEG_CHECK_LAUNCH("wgrad_reduce");
     return MSSEG_OK;
 }
