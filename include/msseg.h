@@ -55,6 +55,8 @@ int msseg_pack_weights(const float* src, void* dst, int dtype, int M, int M0, in
                        int flip, int cout_block, msseg_stream_t stream);
 /* cout block (16/32/48) the igemm kernels use for a layer with M logical output channels */
 int msseg_cout_block(int M);
+/* cout block msseg_conv3d_k3_fwd will use for this problem (pack the weights with it) */
+int msseg_conv3d_k3_cout_block(int N, int D, int H, int W, int Cout);
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolutions (forward-shaped).  y = conv(x, W) + bias.

@@ -40,6 +40,7 @@ struct IgemmParams {
     int creal;           // deconv modes: real channel count of the fine tensor
     int vec_store;       // y / ldy allow 4-element vector stores
     int rel32_ok;        // halo-relative element offsets fit 32 bits (precomputed-offset staging path)
+    int cout_block;      // 0 = msseg_cout_block(M)
     float* stats;        // optional fused per-(n, cout) (sum, sum of squares) of the stored output
     float* stats_ws;     // scratch partials
     unsigned int* counter;
@@ -474,7 +475,7 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
 
 template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int STRIDE = 1>
 int launch_nt(IgemmParams& p, hipStream_t stream) {
-    const int cb = msseg_cout_block(p.M);
+    const int cb = p.cout_block ? p.cout_block : msseg_cout_block(p.M);
     switch (cb) {
         case 16: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 1, STRIDE>(p, stream);
         case 32: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 2, STRIDE>(p, stream);
@@ -483,10 +484,28 @@ int launch_nt(IgemmParams& p, hipStream_t stream) {
     MSSEG_FAIL(MSSEG_EINVAL, "igemm: bad cout block %d", cb);
 }
 
+// Tile / cout-block choice for a conv k3 problem: the largest tile that still yields >= ~3/4 of a chip of
+// workgroups; tiny grids (6^3 .. 12^3 with many channels) drop to 16-wide cout blocks to expose more parallelism
+// (those layers are latency-bound chains of weight-block loads, not MFMA-bound).  cfg: 0 big, 1 mid, 2 small.
+static void k3_plan(int N, int D, int H, int W, int M, int* cfg, int* cb) {
+    const int mn = D < H ? (D < W ? D : W) : (H < W ? H : W);
+    const int std_cb = msseg_cout_block(M);
+    const long long want = (long long)msseg_num_cus() * 3 / 4;
+    auto wgs = [&](int td, int th, int tw, int c) {
+        return (long long)N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw) * ceil_div(M, c);
+    };
+    if (mn >= 32 && wgs(4, 8, 16, std_cb) >= want) { *cfg = 0; *cb = std_cb; return; }
+    if (mn >= 12 && wgs(4, 4, 8, std_cb) >= want) { *cfg = 1; *cb = std_cb; return; }
+    *cfg = 2;
+    *cb = (wgs(2, 4, 8, std_cb) >= want || std_cb == 16) ? std_cb : 16;
+}
+
 template <typename T> int launch_k3(IgemmParams& p, hipStream_t stream) {
-    const int mn = p.D < p.H ? (p.D < p.W ? p.D : p.W) : (p.H < p.W ? p.H : p.W);
-    if (mn >= 32) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8>(p, stream);
-    if (mn >= 12) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 4, 8, 4>(p, stream);
+    int cfg, cb;
+    k3_plan(p.N, p.D, p.H, p.W, p.M, &cfg, &cb);
+    p.cout_block = cb;
+    if (cfg == 0) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8>(p, stream);
+    if (cfg == 1) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 4, 8, 4>(p, stream);
     return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 2, 4, 8, 4>(p, stream);
 }
 
@@ -512,6 +531,12 @@ int msseg_cout_block(int M) {
     if (M % 32 == 0) return 32;
     if (M % 48 == 0) return 48;
     return 32;
+}
+
+int msseg_conv3d_k3_cout_block(int N, int D, int H, int W, int Cout) {
+    int cfg, cb;
+    k3_plan(N, D, H, W, Cout, &cfg, &cb);
+    return cb;
 }
 
 int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,

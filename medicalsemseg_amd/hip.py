@@ -30,6 +30,7 @@ SIGNATURES = {
     "msseg_packed_weight_bytes": ([_i, _i, _i, _i, _i], _sz),
     "msseg_pack_weights": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp], _i),
     "msseg_cout_block": ([_i], _i),
+    "msseg_conv3d_k3_cout_block": ([_i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_reduce_scratch_bytes": ([], _sz),
     "msseg_conv3d_k3s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -158,11 +159,15 @@ def cout_block(M: int) -> int:
     return lib().msseg_cout_block(M)
 
 
+def conv_k3_cout_block(N, D, H, W, cout) -> int:
+    return lib().msseg_conv3d_k3_cout_block(N, D, H, W, cout)
+
+
 def pack_weights(src: torch.Tensor, dtype: torch.dtype, M, M0, T, K, K0, s_m1, s_m0, s_t, s_k1, s_k0, flip=False,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, cb: Optional[int] = None) -> torch.Tensor:
     _need_gpu(src)
     assert src.dtype == torch.float32 and src.is_contiguous()
-    cb = cout_block(M)
+    cb = cb or cout_block(M)
     nbytes = lib().msseg_packed_weight_bytes(M, T, K, cb, _DT[dtype])
     esz = 4 if dtype == torch.float32 else 2
     if out is None:
@@ -173,12 +178,15 @@ def pack_weights(src: torch.Tensor, dtype: torch.dtype, M, M0, T, K, K0, s_m1, s
     return out
 
 
-def pack_conv_k3(w: torch.Tensor, dtype, dgrad=False, out=None):
-    """w: [Cout, Cin, 3,3,3] fp32.  Forward image W[co][tap][ci]; dgrad image W'[ci][26-tap][co]."""
+def pack_conv_k3(w: torch.Tensor, dtype, dgrad=False, out=None, vol=None):
+    """w: [Cout, Cin, 3,3,3] fp32.  Forward image W[co][tap][ci]; dgrad image W'[ci][26-tap][co].
+    vol = (N, D, H, W) of the stride-1 problem the image will be used for (selects the cout block)."""
     co, ci = w.shape[0], w.shape[1]
     if not dgrad:
-        return pack_weights(w, dtype, co, co, 27, ci, ci, 0, ci * 27, 1, 0, 27, False, out)
-    return pack_weights(w, dtype, ci, ci, 27, co, co, 0, 27, 1, 0, ci * 27, True, out)
+        cb = conv_k3_cout_block(*vol, co) if vol is not None else None
+        return pack_weights(w, dtype, co, co, 27, ci, ci, 0, ci * 27, 1, 0, 27, False, out, cb)
+    cb = conv_k3_cout_block(*vol, ci) if vol is not None else None
+    return pack_weights(w, dtype, ci, ci, 27, co, co, 0, 27, 1, 0, ci * 27, True, out, cb)
 
 
 def pack_conv_k1(w: torch.Tensor, dtype, dgrad=False, out=None):

@@ -77,7 +77,8 @@ class Conv3:
             wp = self.cache.get(self.w, dtype, "g", lambda: hip.pack_conv_gather(self.w.detach(), dtype))
             hip.conv3d_gather(x, wp, self.b, y, self.cin, self.cout, 3, 1, 1)
         else:
-            wp = self.cache.get(self.w, dtype, "f", lambda: hip.pack_conv_k3(self.w.detach(), dtype))
+            vol = tuple(x.shape[:4])
+            wp = self.cache.get(self.w, dtype, ("f", vol), lambda: hip.pack_conv_k3(self.w.detach(), dtype, vol=vol))
             if want_stats and x.shape[0] <= 8:
                 stats = torch.empty(x.shape[0], self.cout, 2, dtype=torch.float32, device=x.device)
             hip.conv3d_k3(x, wp, self.b, y, self.cin, self.cout, stats)
@@ -106,7 +107,9 @@ class Conv3:
             return None
         if self._gather(dtype):
             raise NotImplementedError("input gradient of a few-channel stem conv is never needed on this path")
-        wp = self.cache.get(self.w, dtype, "d", lambda: hip.pack_conv_k3(self.w.detach(), dtype, dgrad=True))
+        vol = tuple(dy.shape[:4])
+        wp = self.cache.get(self.w, dtype, ("d", vol),
+                            lambda: hip.pack_conv_k3(self.w.detach(), dtype, dgrad=True, vol=vol))
         dx = dx_out if dx_out is not None else _empty_like_vol(dy, self.cin)
         hip.conv3d_k3(dy, wp, None, dx, self.cout, self.cin)
         return dx

@@ -129,11 +129,12 @@ class Conv3Fn(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         T = x.dtype
         B, D, H, W, _ = x.shape
-        wp = hip.pack_conv_k3(weight.detach().contiguous(), T)
         if stride == 1:
+            wp = hip.pack_conv_k3(weight.detach().contiguous(), T, vol=(B, D, H, W))
             y = torch.empty(B, D, H, W, cout, dtype=T, device=x.device)
             hip.conv3d_k3(x, wp, bias, y, cin, cout)
         else:
+            wp = hip.pack_conv_k3(weight.detach().contiguous(), T)
             y = torch.empty(B, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1, cout, dtype=T, device=x.device)
             hip.conv3d_k3s2(x, wp, bias, y, cin, cout)
         ctx.save_for_backward(x, weight)
@@ -156,7 +157,7 @@ class Conv3Fn(torch.autograd.Function):
             dy = dyz
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wpd = hip.pack_conv_k3(weight.detach().contiguous(), T, dgrad=True)
+            wpd = hip.pack_conv_k3(weight.detach().contiguous(), T, dgrad=True, vol=tuple(dy.shape[:4]))
             dx = torch.empty_like(x)
             hip.conv3d_k3(dy, wpd, None, dx, cout, cin)
         if ctx.needs_input_grad[1]:

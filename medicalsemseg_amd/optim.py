@@ -99,6 +99,22 @@ class FlatAdamW(torch.optim.Optimizer):
         self._gscale.copy_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
         return total
 
+    def state_dict(self):
+        return {"flat": True, "step": self._step, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        if not sd.get("flat"):
+            raise ValueError("not a FlatAdamW state dict")
+        self._step = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self._hyper[1:2].fill_(float(self._step))
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+        # parameters may have been re-loaded (load_state_dict copies into the flat views in place)
+        layers.bump_weights_epoch()
+
     def sync_lr(self):
         """push the host learning rate to the device copy (call between graph replays when the schedule moves)."""
         lr = float(self.param_groups[0]["lr"])

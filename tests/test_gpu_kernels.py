@@ -91,7 +91,7 @@ def test_conv3d_k3_channel_slices(dtype):
     big_in = torch.zeros(1, 8, 8, 16, 64, dtype=dtype, device=dev)
     big_in[..., 32:] = cl(x, dtype, dev)
     big_out = torch.full((1, 8, 8, 16, 48), 7.0, dtype=dtype, device=dev)
-    wp = hip.pack_conv_k3(w.to(dev), dtype)
+    wp = hip.pack_conv_k3(w.to(dev), dtype, vol=(1, 8, 8, 16))
     hip.conv3d_k3(big_in[..., 32:], wp, None, big_out[..., 16:32], 32, 16)
     check(ncdhw(big_out[..., 16:32]), yref, dtype, "conv slice out")
     assert float((big_out[..., :16].float() - 7).abs().max()) == 0 and float((big_out[..., 32:].float() - 7).abs().max()) == 0
@@ -351,7 +351,7 @@ def test_conv3d_k3_fused_stats(dtype, cin, cout, sp, N):
     w = gen(cout, cin, 3, 3, 3, seed=2, scale=(cin * 27) ** -0.5)
     b = gen(cout, seed=3)
     xg = cl(x, dtype, dev)
-    wp = hip.pack_conv_k3(w.to(dev), dtype)
+    wp = hip.pack_conv_k3(w.to(dev), dtype, vol=(N, *sp))
     y = torch.empty(N, *sp, cout, dtype=dtype, device=dev)
     stats = torch.full((N, cout, 2), float("nan"), device=dev)
     for _ in range(3):   # the scratch counter must come back to zero after every launch

@@ -17,7 +17,7 @@ x = torch.randn(N, size, size, size, cin, device=dev).to(dt)
 dy = torch.randn(N, size, size, size, cout, device=dev).to(dt)
 w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
 y = torch.empty(N, size, size, size, cout, dtype=dt, device=dev)
-wp = hip.pack_conv_k3(w, dt)
+wp = hip.pack_conv_k3(w, dt, vol=(N, size, size, size))
 dw = torch.empty_like(w)
 stats = torch.empty(N, cout, 2, device=dev)
 flops = 2.0 * N * size ** 3 * 27 * cin * cout
