@@ -18,6 +18,8 @@
 // ConvTranspose k2 s2 forward (1x1 GEMM + pixel-shuffle scatter) and its input gradient (gather).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 enum { SRC_DIRECT = 0, SRC_GATHER = 1, SRC_DECONV_BWD = 2 };
@@ -46,7 +48,7 @@ struct IgemmParams {
     unsigned int* counter;
 };
 
-template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1>
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1, int NSL = 1>
 struct IgemmCfg {
     static constexpr int EPC = DT<T>::EPC;
     static constexpr int CB = 4 * EPC;
@@ -61,7 +63,11 @@ struct IgemmCfg {
     static constexpr int COUTB = NT * 16;
     static constexpr int PLANE = ((HV * 16 + 255) / 256) * 256;
     static constexpr int A_BYTES = ((4 * PLANE + 64 + 255) / 256) * 256;
-    static constexpr int B_BYTES = NTAPS * 4 * COUTB * 16;
+    // NSL > 1: the weight image is staged in NSL tap slices (one kd plane each) instead of all 27 taps, which
+    // brings the workgroup under 80 KB of LDS so that two workgroups share a CU and fill each other's bubbles
+    static constexpr int BT = NTAPS / NSL;
+    static constexpr int B_BYTES = BT * 4 * COUTB * 16;
+    static_assert(NTAPS % NSL == 0, "tap slices must divide the taps");
     static constexpr int STAT_FLOATS = MSSEG_STATS_NMAX * COUTB * 2;
     static constexpr int STAT_BYTES = (EPI == EPI_STORE) ? (STAT_FLOATS + WAVES * COUTB * 2) * 4 + 256 : 0;
     static constexpr int LDS_BYTES = A_BYTES + B_BYTES + STAT_BYTES;
@@ -70,9 +76,10 @@ struct IgemmCfg {
 
 MSSEG_DEVFN int aoff(int q, int plane) { return q * plane + (q >> 1) * 32; }
 
-template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1>
-__global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams p) {
-    using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE>;
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1, int NSL = 1>
+__global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kernel(const IgemmParams p) {
+    using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE, NSL>;
+    constexpr int BT = C::BT;
     constexpr int EPC = C::EPC, CB = C::CB, PAD = C::PAD, PH = C::PH, PW = C::PW, HV = C::HV, MT = C::MT;
     constexpr int NTHREADS = C::NTHREADS, COUTB = C::COUTB, PLANE = C::PLANE;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -222,7 +229,8 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
             a_pk[it] = (i < HV * 4) ? (hd | (hh << 8) | (hw << 16)) : -1;
         }
     }
-    auto fetch = [&](const TileCo& tc, int kb, bool with_b) {
+    auto fetch = [&](const TileCo& tc, int kb, int ks, bool with_a, bool with_b) {
+        if (with_a) {
         if constexpr (SRC == SRC_DIRECT) {
             if (p.rel32_ok) {
                 const int dB = tc.d0 * STRIDE - PAD, hB = tc.h0 * STRIDE - PAD, wB = tc.w0 * STRIDE - PAD;
@@ -233,12 +241,20 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
                 const bool cok = (tid & 3) < nchunk;
                 if (interior) {
 #pragma unroll
-                    for (int it = 0; it < NIT_A; ++it)
-                        pa[it] = (cok && a_pk[it] >= 0) ? *(const u32x4_t*)(bp + a_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
+                    for (int it = 0; it < NIT_A; ++it) {
+                        const bool valid = (NSL > 1) ? (tid + it * NTHREADS < HV * 4) : (a_pk[it] >= 0);
+                        pa[it] = (cok && valid) ? *(const u32x4_t*)(bp + a_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
+                    }
                 } else {
 #pragma unroll
                     for (int it = 0; it < NIT_A; ++it) {
-                        const int pk = a_pk[it];
+                        int pk = a_pk[it];
+                        if constexpr (NSL > 1) {   // register-lean variant: recompute the halo coordinates
+                            const int i = tid + it * NTHREADS;
+                            const int hv = i >> 2;
+                            const int hw = hv % PW, t2 = hv / PW;
+                            pk = (i < HV * 4) ? ((t2 / PH) | ((t2 % PH) << 8) | (hw << 16)) : -1;
+                        }
                         const int d = dB + (pk & 255), h = hB + ((pk >> 8) & 255), w = wB + ((pk >> 16) & 255);
                         const bool ok = cok && pk >= 0 && (unsigned)d < (unsigned)XD && (unsigned)h < (unsigned)XH &&
                                         (unsigned)w < (unsigned)XW;
@@ -259,8 +275,10 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
                 pa[it] = (i < HV * 4) ? load_a_chunk(tc, kb, i) : u32x4_t{0u, 0u, 0u, 0u};
             }
         }
+        }
         if (with_b) {
-            const u32x4_t* src = (const u32x4_t*)((const unsigned char*)p.wp + ((long long)coutblk * p.NKB + kb) * C::B_BYTES);
+            const u32x4_t* src = (const u32x4_t*)((const unsigned char*)p.wp +
+                                                  (((long long)coutblk * p.NKB + kb) * NSL + ks) * C::B_BYTES);
 #pragma unroll
             for (int it = 0; it < NIT_B; ++it) {
                 const int i = tid + it * NTHREADS;
@@ -268,11 +286,13 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
             }
         }
     };
-    auto commit = [&](bool with_b) {
+    auto commit = [&](bool with_a, bool with_b) {
+        if (with_a) {
 #pragma unroll
-        for (int it = 0; it < NIT_A; ++it) {
-            const int i = tid + it * NTHREADS;
-            if (i < HV * 4) *(u32x4_t*)(ldsA + aoff(i & 3, PLANE) + (i >> 2) * 16) = pa[it];
+            for (int it = 0; it < NIT_A; ++it) {
+                const int i = tid + it * NTHREADS;
+                if (i < HV * 4) *(u32x4_t*)(ldsA + aoff(i & 3, PLANE) + (i >> 2) * 16) = pa[it];
+            }
         }
         if (with_b) {
 #pragma unroll
@@ -284,22 +304,28 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
     };
 
     f32x4_t acc[MT][NT];
-    int tile = blockIdx.x, kb = 0;
+    int tile = blockIdx.x, kb = 0, ks = 0;
     TileCo tc = decode(tile < p.ntiles ? tile : 0);
-    bool b_pending = true;
-    if (tile < p.ntiles) fetch(tc, 0, true);
+    bool a_pending = true, b_pending = true;
+    if (tile < p.ntiles) fetch(tc, 0, 0, true, true);
     while (tile < p.ntiles) {
         __syncthreads();  // everyone finished reading the previous stage's LDS image
-        commit(b_pending);
+        commit(a_pending, b_pending);
         __syncthreads();
-        int ntile = tile, nkb = kb + 1;
-        if (nkb == p.NKB) { nkb = 0; ntile = tile + gridDim.x; }
+        // next stage: (tile, kb, ks) advance ks fastest
+        int ntile = tile, nkb = kb, nks = ks + 1;
+        if (nks == NSL) {
+            nks = 0;
+            nkb = kb + 1;
+            if (nkb == p.NKB) { nkb = 0; ntile = tile + gridDim.x; }
+        }
         const TileCo ntc = decode(ntile < p.ntiles ? ntile : 0);
-        b_pending = p.NKB > 1;
-        if (ntile < p.ntiles) fetch(ntc, nkb, b_pending);
+        a_pending = nks == 0;
+        b_pending = NSL > 1 || p.NKB > 1;
+        if (ntile < p.ntiles) fetch(ntc, nkb, nks, a_pending, b_pending);
 
         const int n = tc.n, d0 = tc.d0, h0 = tc.h0, w0 = tc.w0;
-        if (kb == 0) {
+        if (kb == 0 && ks == 0) {
             if constexpr (EPI == EPI_STORE) {
                 if (do_stats && n != cur_n) {
                     if (cur_n >= 0) flush_stats(cur_n);
@@ -312,33 +338,48 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
                 for (int j = 0; j < NT; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
         // ---------------- MFMA ----------------
-        // Operand fragments are double-buffered in registers: the 6 LDS reads of tap t+1 are issued before the
+        // Operand fragments are double-buffered in registers: the LDS reads of tap t+1 are issued before the
         // MFMAs of tap t, so the matrix pipe runs under one full LDS latency instead of waiting for it per pair.
         {
             u32x4_t af[2][MT], bf[2][NT];
-            auto load_frags = [&](int tap, int buf) {
-                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int ksoff = (NSL > 1) ? ks * (PH * PW * 16) : 0;   // slice ks = kd plane ks of the halo
+            auto load_frags = [&](int t, int buf) {
+                const int tap = (NSL > 1) ? t : t;   // local tap within the slice; (kh, kw) from t when sliced by kd
+                const int kd = (NSL > 1) ? 0 : tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
                 const int toff = (NTAPS == 27) ? ((kd * PH + kh) * PW + kw) * 16 : 0;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    bf[buf][j] = *(const u32x4_t*)(ldsB + bbase + tap * (4 * COUTB * 16) + j * 256);
+                    bf[buf][j] = *(const u32x4_t*)(ldsB + bbase + t * (4 * COUTB * 16) + j * 256);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) af[buf][m] = *(const u32x4_t*)(ldsA + abase[m] + toff);
+                for (int m = 0; m < MT; ++m) af[buf][m] = *(const u32x4_t*)(ldsA + abase[m] + ksoff + toff);
             };
-            load_frags(0, 0);
+            if constexpr (NSL == 1) {
+                load_frags(0, 0);
 #pragma unroll
-            for (int tap = 0; tap < NTAPS; ++tap) {
-                const int cur = tap & 1;
-                if (tap + 1 < NTAPS) load_frags(tap + 1, cur ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < BT; ++t) {
+                    const int cur = t & 1;
+                    if (t + 1 < BT) load_frags(t + 1, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) mma_chunk<T>(acc[m][j], bf[cur][j], af[cur][m]);
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int j = 0; j < NT; ++j) mma_chunk<T>(acc[m][j], bf[cur][j], af[cur][m]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // two workgroups share the CU in this variant: the other workgroup's waves cover LDS latency, so the
+                // fragments are single-buffered to stay within 256 VGPRs (2 waves per SIMD)
+#pragma unroll
+                for (int t = 0; t < BT; ++t) {
+                    load_frags(t, 0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) mma_chunk<T>(acc[m][j], bf[0][j], af[0][m]);
+                }
             }
         }
-        if (kb == p.NKB - 1) {
+        if (kb == p.NKB - 1 && ks == NSL - 1) {
             // ---------------- epilogue ----------------
     #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -399,7 +440,7 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
                 }
             }
         }
-        tile = ntile; kb = nkb; tc = ntc;
+        tile = ntile; kb = nkb; ks = nks; tc = ntc;
     }
     if constexpr (EPI == EPI_STORE) {
         if (do_stats) {
@@ -439,9 +480,9 @@ __global__ __launch_bounds__(WAVES * 64) void igemm_fwd_kernel(const IgemmParams
     }
 }
 
-template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1>
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1, int NSL = 1>
 int launch_cfg(IgemmParams& p, hipStream_t stream) {
-    using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE>;
+    using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE, NSL>;
     p.tiles_d = ceil_div(p.D, TD);
     p.tiles_h = ceil_div(p.H, TH);
     p.tiles_w = ceil_div(p.W, TW);
@@ -454,7 +495,7 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
         const long long xh = STRIDE == 1 ? p.H : p.IH, xw = STRIDE == 1 ? p.W : p.IW;
         p.rel32_ok = ((long long)(C::PD + 1) * xh * xw * p.ldx < 0x7fffffffLL) ? 1 : 0;
     }
-    auto kern = igemm_fwd_kernel<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE>;
+    auto kern = igemm_fwd_kernel<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE, NSL>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) !=
@@ -473,13 +514,13 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
     return MSSEG_OK;
 }
 
-template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int STRIDE = 1>
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int STRIDE = 1, int NSL = 1>
 int launch_nt(IgemmParams& p, hipStream_t stream) {
     const int cb = p.cout_block ? p.cout_block : msseg_cout_block(p.M);
     switch (cb) {
-        case 16: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 1, STRIDE>(p, stream);
-        case 32: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 2, STRIDE>(p, stream);
-        case 48: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 3, STRIDE>(p, stream);
+        case 16: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 1, STRIDE, NSL>(p, stream);
+        case 32: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 2, STRIDE, NSL>(p, stream);
+        case 48: return launch_cfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, 3, STRIDE, NSL>(p, stream);
     }
     MSSEG_FAIL(MSSEG_EINVAL, "igemm: bad cout block %d", cb);
 }
@@ -504,7 +545,11 @@ template <typename T> int launch_k3(IgemmParams& p, hipStream_t stream) {
     int cfg, cb;
     k3_plan(p.N, p.D, p.H, p.W, p.M, &cfg, &cb);
     p.cout_block = cb;
-    if (cfg == 0) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8>(p, stream);
+    if (cfg == 0) {
+        static const bool old_big = getenv("MSSEG_K3_BIG_OLD") != nullptr;   // A/B switch: 1 WG/CU, all taps resident
+        if (old_big || cb == 48) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8>(p, stream);  // 48-wide: sliced variant spills
+        return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 2, 8, 16, 4, 1, 3>(p, stream);
+    }
     if (cfg == 1) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 4, 8, 4>(p, stream);
     return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 2, 4, 8, 4>(p, stream);
 }
