@@ -57,6 +57,8 @@ int msseg_pack_weights(const float* src, void* dst, int dtype, int M, int M0, in
 int msseg_cout_block(int M);
 /* cout block msseg_conv3d_k3_fwd will use for this problem (pack the weights with it) */
 int msseg_conv3d_k3_cout_block(int N, int D, int H, int W, int Cout);
+/* tile variant it will use: 0 = 4x8x16-voxel tiles / 8 waves (the MFMA-bound large layers), 1 = 4x4x8, 2 = 2x4x8 */
+int msseg_conv3d_k3_variant(int N, int D, int H, int W, int Cout);
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolutions (forward-shaped).  y = conv(x, W) + bias.

@@ -546,7 +546,9 @@ template <typename T> int launch_k3(IgemmParams& p, hipStream_t stream) {
     k3_plan(p.N, p.D, p.H, p.W, p.M, &cfg, &cb);
     p.cout_block = cb;
     if (cfg == 0) {
-        static const bool old_big = getenv("MSSEG_K3_BIG_OLD") != nullptr;   // A/B switch: 1 WG/CU, all taps resident
+        // A/B switch.  Measured on MI355X (round 1): the tap-sliced 2-WG/CU variant is SLOWER (32->32 @96^3: 144 us
+        // vs 110 us) -- weight-slice refetch + 3x barriers cost more than the second workgroup hides.
+        static const bool old_big = getenv("MSSEG_K3_SLICED") == nullptr;
         if (old_big || cb == 48) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8>(p, stream);  // 48-wide: sliced variant spills
         return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 2, 8, 16, 4, 1, 3>(p, stream);
     }
@@ -582,6 +584,12 @@ int msseg_conv3d_k3_cout_block(int N, int D, int H, int W, int Cout) {
     int cfg, cb;
     k3_plan(N, D, H, W, Cout, &cfg, &cb);
     return cb;
+}
+
+int msseg_conv3d_k3_variant(int N, int D, int H, int W, int Cout) {
+    int cfg, cb;
+    k3_plan(N, D, H, W, Cout, &cfg, &cb);
+    return cfg;
 }
 
 int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,

@@ -31,6 +31,7 @@ SIGNATURES = {
     "msseg_pack_weights": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp], _i),
     "msseg_cout_block": ([_i], _i),
     "msseg_conv3d_k3_cout_block": ([_i, _i, _i, _i, _i], _i),
+    "msseg_conv3d_k3_variant": ([_i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_reduce_scratch_bytes": ([], _sz),
     "msseg_conv3d_k3s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -273,7 +274,10 @@ def conv3d_k3(x, wp, bias, y, cin, cout, stats=None):
     def go():
         _ck(lib().msseg_conv3d_k3_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, _p(stats),
                                       _p(sc), sc.numel() if sc is not None else 0, dt(x), _stream()), "conv3d_k3_fwd")
-    TIMER.launch("conv3d_k3_fwd", 2.0 * nv * 27 * cin * cout, nv * (cin + cout) * esz + 27 * cin * cout * esz, go)
+    key = "conv3d_k3_fwd"
+    if TIMER.enabled:
+        key += "/v%d" % lib().msseg_conv3d_k3_variant(N, D, H, W, cout)
+    TIMER.launch(key, 2.0 * nv * 27 * cin * cout, nv * (cin + cout) * esz + 27 * cin * cout * esz, go)
     return y
 
 
