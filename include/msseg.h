@@ -70,6 +70,15 @@ int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const floa
                         int N, int D, int H, int W, int Cin, int Cout, float* stats /* nullable: fused InstanceNorm
                         statistics stats[n][cout][2] = (sum, sum of squares) of y as stored; needs N <= 8 */,
                         void* scratch, size_t scratch_bytes, int dtype, msseg_stream_t stream);
+/* Input gradient of a conv k3 (dgrad-packed weights) FUSED with the InstanceNorm-backward reductions of the layer
+ * whose activation receives that gradient: da = conv(dy, W'); red[n][c] = (sum dz, sum dz*xhat) with
+ * dz = da*lrelu'(act), xhat from (yraw, fwd_stats); dbeta/dgamma (nullable) = sum_n red (written or accumulated).
+ * Saves the separate msseg_instnorm_act_bwd_reduce pass (3 tensor reads).  N <= 8, Cout % 4 == 0. */
+int msseg_conv3d_k3_dgrad_inbwd(const void* dy, long long lddy, const void* wp, void* da, long long ldda, int N, int D,
+                                int H, int W, int Cin, int Cout, const void* yraw, long long ldyraw, const void* act,
+                                long long ldact, const float* fwd_stats, float slope, float eps, float* red,
+                                float* dgamma, float* dbeta, int accumulate, void* scratch, size_t scratch_bytes,
+                                int dtype, msseg_stream_t stream);
 /* Conv3d k=3 s=2 p=1 (PatchMerging.reduction, models/backbones/swin_nnformer.py:297): x [N,ID,IH,IW,Cin] ->
  * y [N,(ID-1)/2+1,...,Cout].  Its input / weight gradients run as stride-1 problems on msseg_zero_stuff2(dy). */
 int msseg_conv3d_k3s2_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,

@@ -46,6 +46,14 @@ struct IgemmParams {
     float* stats;        // optional fused per-(n, cout) (sum, sum of squares) of the stored output
     float* stats_ws;     // scratch partials
     unsigned int* counter;
+    // optional fused InstanceNorm-BACKWARD reductions: this launch produces da (gradient w.r.t. the activation
+    // a = lrelu(IN(yraw))); the epilogue then accumulates red[n][c] = (sum dz, sum dz*xhat), dz = da*lrelu'(a), into
+    // `stats`, and the finalising block also emits dbeta / dgamma.
+    const void* nb_y; long long nb_ldy;
+    const void* nb_a; long long nb_lda;
+    const float* nb_stats;   // [N][M][2] forward statistics (sum, sum of squares) of yraw
+    float nb_slope, nb_eps; long long nb_S;
+    float* nb_dgamma; float* nb_dbeta; int nb_acc;
 };
 
 template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1, int NSL = 1>
@@ -429,11 +437,33 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
                     }
                     if constexpr (EPI == EPI_STORE) {
                         if (do_stats) {
+                            if (p.nb_y == nullptr) {
     #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float rv = (float)(T)o[e];  // statistics of the tensor as stored
-                                st[j][e] += rv;
-                                st2[j][e] += rv * rv;
+                                for (int e = 0; e < 4; ++e) {
+                                    const float rv = (float)(T)o[e];  // statistics of the tensor as stored
+                                    st[j][e] += rv;
+                                    st2[j][e] += rv * rv;
+                                }
+                            } else if (co + 4 <= p.M) {
+                                // dz = da * lrelu'(a);  accumulate (sum dz, sum dz * yraw); xhat is formed at the end:
+                                // sum dz*xhat = rstd * (sum dz*yraw - mean * sum dz)
+                                f32x4_t yv, av;
+                                if constexpr (sizeof(T) == 2) {
+                                    const bf16x4_t y4 = *(const bf16x4_t*)((const T*)p.nb_y + vox * p.nb_ldy + co);
+                                    const bf16x4_t a4 = *(const bf16x4_t*)((const T*)p.nb_a + vox * p.nb_lda + co);
+    #pragma unroll
+                                    for (int e = 0; e < 4; ++e) { yv[e] = (float)y4[e]; av[e] = (float)a4[e]; }
+                                } else {
+                                    yv = *(const f32x4_t*)((const T*)p.nb_y + vox * p.nb_ldy + co);
+                                    av = *(const f32x4_t*)((const T*)p.nb_a + vox * p.nb_lda + co);
+                                }
+    #pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float da = (float)(T)o[e];
+                                    const float dz = av[e] > 0.f ? da : da * p.nb_slope;
+                                    st[j][e] += dz;
+                                    st2[j][e] += dz * yv[e];
+                                }
                             }
                         }
                     }
@@ -451,28 +481,49 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
             for (int i = tid; i < PN; i += NTHREADS) wsp[i] = spart[i];
             int* flag = (int*)(wpart + WAVES * COUTB * 2);
             if (grid_last_block(p.counter, gridDim.x * gridDim.y, flag)) {
-                // 16 lanes share one output, every lane keeps up to 16 loads in flight; fixed summation order
+                // 16 lanes share one (cout) output pair, every lane keeps up to 16 loads in flight; fixed order
                 constexpr int PARTS = 16;
-                const int nout = gridDim.y * PN;
+                const int nch = gridDim.y * COUTB;
                 const int sub = tid % PARTS;
-                for (int base = 0; base < nout; base += NTHREADS / PARTS) {
+                for (int base = 0; base < nch; base += NTHREADS / PARTS) {
                     const int o = base + tid / PARTS;
-                    float s = 0.f;
-                    const bool ok = o < nout;
-                    const int y = ok ? o / PN : 0, i = ok ? o % PN : 0;
-                    if (ok) {
-                        const float* src = p.stats_ws + (long long)y * gridDim.x * PN + i;
-#pragma unroll 16
-                        for (int x = sub; x < (int)gridDim.x; x += PARTS) s += src[(long long)x * PN];
+                    const bool ok = o < nch;
+                    const int y = ok ? o / COUTB : 0, cl = ok ? o % COUTB : 0;
+                    const int cg = y * COUTB + cl;
+                    float g0 = 0.f, g1 = 0.f;
+                    for (int nn = 0; nn < p.N; ++nn) {
+                        float s0 = 0.f, s1 = 0.f;
+                        if (ok) {
+                            const float* src = p.stats_ws + (long long)y * gridDim.x * PN + (nn * COUTB + cl) * 2;
+#pragma unroll 8
+                            for (int x = sub; x < (int)gridDim.x; x += PARTS) {
+                                s0 += src[(long long)x * PN];
+                                s1 += src[(long long)x * PN + 1];
+                            }
+                        }
+#pragma unroll
+                        for (int o2 = 1; o2 < PARTS; o2 <<= 1) {
+                            s0 += __shfl_xor(s0, o2);
+                            s1 += __shfl_xor(s1, o2);
+                        }
+                        if (ok && sub == 0 && cg < p.M) {
+                            if (p.nb_y != nullptr) {
+                                const float inv = 1.0f / (float)p.nb_S;
+                                const float fs = p.nb_stats[((long long)nn * p.M + cg) * 2], fs2 = p.nb_stats[((long long)nn * p.M + cg) * 2 + 1];
+                                const float mean = fs * inv;
+                                float var = fs2 * inv - mean * mean;
+                                var = var > 0.f ? var : 0.f;
+                                s1 = rsqrtf(var + p.nb_eps) * (s1 - mean * s0);
+                                g0 += s0;
+                                g1 += s1;
+                            }
+                            p.stats[((long long)nn * p.M + cg) * 2 + 0] = s0;
+                            p.stats[((long long)nn * p.M + cg) * 2 + 1] = s1;
+                        }
                     }
-                    s += __shfl_xor(s, 1);
-                    s += __shfl_xor(s, 2);
-                    s += __shfl_xor(s, 4);
-                    s += __shfl_xor(s, 8);
-                    if (ok && sub == 0) {
-                        const int k = i & 1, cl = (i >> 1) % COUTB, nn = i / (2 * COUTB);
-                        const int cg = y * COUTB + cl;
-                        if (cg < p.M) p.stats[((long long)nn * p.M + cg) * 2 + k] = s;
+                    if (ok && sub == 0 && cg < p.M && p.nb_y != nullptr && p.nb_dgamma != nullptr) {
+                        p.nb_dbeta[cg] = p.nb_acc ? p.nb_dbeta[cg] + g0 : g0;
+                        p.nb_dgamma[cg] = p.nb_acc ? p.nb_dgamma[cg] + g1 : g1;
                     }
                 }
             }
@@ -592,9 +643,38 @@ int msseg_conv3d_k3_variant(int N, int D, int H, int W, int Cout) {
     return cfg;
 }
 
+static int k3_fwd_impl(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy, int N,
+                       int D, int H, int W, int Cin, int Cout, float* stats, void* scratch, size_t scratch_bytes,
+                       const void* nb_y, long long nb_ldy, const void* nb_a, long long nb_lda, const float* nb_stats,
+                       float nb_slope, float nb_eps, float* nb_dgamma, float* nb_dbeta, int nb_acc, int dtype,
+                       msseg_stream_t stream);
+
 int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                         int N, int D, int H, int W, int Cin, int Cout, float* stats, void* scratch,
                         size_t scratch_bytes, int dtype, msseg_stream_t stream) {
+    return k3_fwd_impl(x, ldx, wp, bias, y, ldy, N, D, H, W, Cin, Cout, stats, scratch, scratch_bytes, nullptr, 0, nullptr,
+                       0, nullptr, 0.f, 0.f, nullptr, nullptr, 0, dtype, stream);
+}
+
+int msseg_conv3d_k3_dgrad_inbwd(const void* dy, long long lddy, const void* wp, void* da, long long ldda, int N, int D,
+                                int H, int W, int Cin, int Cout, const void* yraw, long long ldyraw, const void* act,
+                                long long ldact, const float* fwd_stats, float slope, float eps, float* red,
+                                float* dgamma, float* dbeta, int accumulate, void* scratch, size_t scratch_bytes,
+                                int dtype, msseg_stream_t stream) {
+    if (!yraw || !act || !fwd_stats || !red) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_dgrad_inbwd: null pointer");
+    if ((dgamma == nullptr) != (dbeta == nullptr)) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_dgrad_inbwd: dgamma/dbeta go together");
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    if (Cout % 4 || (ldyraw % 4) || (ldact % 4) || ((uintptr_t)yraw % (4 * esz)) || ((uintptr_t)act % (4 * esz)))
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_dgrad_inbwd: channel count / strides must be multiples of 4");
+    return k3_fwd_impl(dy, lddy, wp, nullptr, da, ldda, N, D, H, W, Cin, Cout, red, scratch, scratch_bytes, yraw, ldyraw,
+                       act, ldact, fwd_stats, slope, eps, dgamma, dbeta, accumulate, dtype, stream);
+}
+
+static int k3_fwd_impl(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy, int N,
+                       int D, int H, int W, int Cin, int Cout, float* stats, void* scratch, size_t scratch_bytes,
+                       const void* nb_y, long long nb_ldy, const void* nb_a, long long nb_lda, const float* nb_stats,
+                       float nb_slope, float nb_eps, float* nb_dgamma, float* nb_dbeta, int nb_acc, int dtype,
+                       msseg_stream_t stream) {
     const int esz = dtype == MSSEG_F32 ? 4 : 2;
     int rc = check_common(x, ldx, wp, y, ldy, dtype, esz);
     if (rc) return rc;
@@ -612,6 +692,9 @@ int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const floa
         p.stats = stats;
         p.counter = (unsigned int*)scratch;
         p.stats_ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+        p.nb_y = nb_y; p.nb_ldy = nb_ldy; p.nb_a = nb_a; p.nb_lda = nb_lda; p.nb_stats = nb_stats;
+        p.nb_slope = nb_slope; p.nb_eps = nb_eps; p.nb_S = (long long)D * H * W;
+        p.nb_dgamma = nb_dgamma; p.nb_dbeta = nb_dbeta; p.nb_acc = nb_acc;
     }
     return dtype == MSSEG_F32 ? launch_k3<float>(p, (hipStream_t)stream) : launch_k3<bf16_t>(p, (hipStream_t)stream);
 }

@@ -34,6 +34,8 @@ SIGNATURES = {
     "msseg_conv3d_k3_variant": ([_i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_reduce_scratch_bytes": ([], _sz),
+    "msseg_conv3d_k3_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll, _vp, _f, _f, _vp,
+                                     _vp, _vp, _i, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_k3s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_zero_stuff2": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_window_attention_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -281,6 +283,29 @@ def conv3d_k3(x, wp, bias, y, cin, cout, stats=None):
     return y
 
 
+def conv3d_k3_dgrad_inbwd(dy, wp, da, cin, cout, yraw, act, fwd_stats, slope, eps, dgamma=None, dbeta=None,
+                          accumulate=False):
+    """da = conv(dy, dgrad image) and, in the same launch, red[N][cout][2] = InstanceNorm-backward reductions of the
+    layer (yraw, act, fwd_stats) that receives da.  Returns red."""
+    _need_gpu(dy, wp, da, yraw, act, fwd_stats)
+    N, D, H, W = dy.shape[:4]
+    nv = N * D * H * W
+    esz = dy.element_size()
+    red = torch.empty(N, cout, 2, dtype=torch.float32, device=dy.device)
+    sc = scratch(dy.device)
+
+    def go():
+        _ck(lib().msseg_conv3d_k3_dgrad_inbwd(_p(dy), ld(dy), _p(wp), _p(da), ld(da), N, D, H, W, cin, cout, _p(yraw),
+                                              ld(yraw), _p(act), ld(act), _p(fwd_stats), slope, eps, _p(red),
+                                              _p(dgamma), _p(dbeta), int(accumulate), _p(sc), sc.numel(), dt(dy),
+                                              _stream()), "conv3d_k3_dgrad_inbwd")
+    key = "conv3d_k3_fwd"
+    if TIMER.enabled:
+        key += "/v%d" % lib().msseg_conv3d_k3_variant(N, D, H, W, cout)
+    TIMER.launch(key, 2.0 * nv * 27 * cin * cout, nv * (cin + 3 * cout) * esz + 27 * cin * cout * esz, go)
+    return red
+
+
 def conv3d_k1(x, wp, bias, y, cin, cout):
     _need_gpu(x, wp, y)
     nv = x.numel() // x.shape[-1]
@@ -408,6 +433,13 @@ def instnorm_act_bwd(x, stats, gamma, y, dy, dx, slope, eps=1e-5, dres=None, dga
     _ck(lib().msseg_instnorm_act_bwd_reduce(_p(x), ld(x), _p(stats), _p(y), ld(y), _p(dy), ld(dy), _p(red),
                                             _p(dgamma), _p(dbeta), int(accumulate), N, S, Cc, eps, slope, _p(sc),
                                             sc.numel(), dt(x), _stream()), "instnorm_act_bwd_reduce")
+    instnorm_act_bwd_apply(x, stats, gamma, y, dy, red, dx, slope, eps, dres)
+    return red
+
+
+def instnorm_act_bwd_apply(x, stats, gamma, y, dy, red, dx, slope, eps=1e-5, dres=None):
+    _need_gpu(x, stats, y, dy, dx, red)
+    N, S, Cc = _nsc(x)
     _ck(lib().msseg_instnorm_act_bwd_apply(_p(x), ld(x), _p(stats), _p(gamma), _p(y), ld(y), _p(dy), ld(dy), _p(red),
                                            _p(dx), ld(dx), _p(dres), ld(dres) if dres is not None else 0, N, S, Cc, eps,
                                            slope, dt(x), _stream()), "instnorm_act_bwd_apply")

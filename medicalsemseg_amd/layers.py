@@ -86,7 +86,9 @@ class Conv3:
             return y, (stats if stats is not None else hip.channel_stats(y))
         return y
 
-    def bwd(self, x, dy, need_dx=True, dx_out=None, bias_grad_is_zero=False):
+    def bwd(self, x, dy, need_dx=True, dx_out=None, bias_grad_is_zero=False, next_norm=None):
+        """next_norm = (InstNormAct, yraw, stats, act) of the layer whose activation is this conv's input: its
+        InstanceNorm-backward reductions are then fused into the input-gradient kernel; returns (dx, red)."""
         dtype = x.dtype
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
@@ -111,6 +113,19 @@ class Conv3:
         wp = self.cache.get(self.w, dtype, ("d", vol),
                             lambda: hip.pack_conv_k3(self.w.detach(), dtype, dgrad=True, vol=vol))
         dx = dx_out if dx_out is not None else _empty_like_vol(dy, self.cin)
+        if next_norm is not None:
+            nrm, yraw, stats, act = next_norm
+            if dy.shape[0] <= 8 and self.cin % 4 == 0:
+                dg = db = None
+                acc = False
+                if nrm.gamma is not None and nrm.gamma.requires_grad:
+                    dg, acc = _grad_buf(nrm.gamma)
+                    db, _ = _grad_buf(nrm.beta)
+                red = hip.conv3d_k3_dgrad_inbwd(dy, wp, dx, self.cout, self.cin, yraw, act, stats, nrm.slope, nrm.eps,
+                                                dg, db, acc)
+                return dx, red
+            hip.conv3d_k3(dy, wp, None, dx, self.cout, self.cin)
+            return dx, None
         hip.conv3d_k3(dy, wp, None, dx, self.cout, self.cin)
         return dx
 
@@ -210,9 +225,13 @@ class InstNormAct:
         hip.instnorm_act_fwd(y_raw, stats, self.gamma, self.beta, a, self.slope, self.eps, residual)
         return a, stats
 
-    def bwd(self, y_raw, stats, a, da, want_dres=False):
+    def bwd(self, y_raw, stats, a, da, want_dres=False, red=None):
+        """red: reductions already produced by the kernel that made `da` (fused path) -> only the apply pass runs"""
         dy = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device)
         dres = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device) if want_dres else None
+        if red is not None:
+            hip.instnorm_act_bwd_apply(y_raw, stats, self.gamma, a, da, red, dy, self.slope, self.eps, dres)
+            return (dy, dres) if want_dres else dy
         dg = db = None
         acc = False
         if self.gamma is not None and self.gamma.requires_grad:
@@ -234,9 +253,15 @@ class ConvNormAct:
         a, stats = self.norm.fwd(y, out, stats=stats)
         return a, (x, y, stats, a)
 
-    def bwd(self, saved, da, need_dx=True):
+    def bwd(self, saved, da, need_dx=True, red=None, next_saved=None, next_cna=None):
+        """red: this layer's IN-backward reductions if the producer of `da` already computed them.
+        next_cna/next_saved: the ConvNormAct (and its saved tuple) whose activation is this conv's input; when given
+        the result is (dx, red_for_that_layer)."""
         x, y, stats, a = saved
-        dy = self.norm.bwd(y, stats, a, da)
+        dy = self.norm.bwd(y, stats, a, da, red=red)
+        if next_cna is not None and need_dx:
+            nx, ny, nstats, na = next_saved
+            return self.conv.bwd(x, dy, True, bias_grad_is_zero=True, next_norm=(next_cna.norm, ny, nstats, na))
         return self.conv.bwd(x, dy, need_dx, bias_grad_is_zero=True)
 
 
@@ -272,8 +297,8 @@ class ResBlock:
     def bwd(self, saved, do, need_dx=True):
         x, y1, s1, a1, y2, s2, y3, s3, r, o = saved
         dy2, dres = self.n2.bwd(y2, s2, o, do, want_dres=True)
-        da1 = self.c2.bwd(a1, dy2, True)
-        dy1 = self.n1.bwd(y1, s1, a1, da1)
+        da1, red1 = self.c2.bwd(a1, dy2, True, next_norm=(self.n1, y1, s1, a1))
+        dy1 = self.n1.bwd(y1, s1, a1, da1, red=red1)
         dx = self.c1.bwd(x, dy1, need_dx)
         if self.c3 is not None:
             dy3 = self.n3.bwd(y3, s3, r, dres)

@@ -185,8 +185,8 @@ class _UNetFn(torch.autograd.Function):
             up, c0, c1 = net._dec[j]
             lvl = 3 - j
             up_in, s0, s1 = saved["dec"][j]
-            g = c1.bwd(s1, g, True)
-            dcat = c0.bwd(s0, g, True)
+            g, red = c1.bwd(s1, g, True, next_saved=s0, next_cna=c0)
+            dcat = c0.bwd(s0, g, True, red=red)
             skip_grads[lvl] = dcat[..., :f[lvl]]
             g = up.bwd(up_in, dcat[..., f[lvl]:], True)
         # encoder, bottom-up
@@ -198,7 +198,7 @@ class _UNetFn(torch.autograd.Function):
                 x_l = s1[3]
                 hip.maxpool2_bwd(x_l, g, skip_grads[lvl], accumulate=True)
                 g = skip_grads[lvl]
-            g = c1.bwd(s1, g, True)
-            g = c0.bwd(s0, g, need_dx=(lvl > 0))
+            g, red = c1.bwd(s1, g, True, next_saved=s0, next_cna=c0)
+            g = c0.bwd(s0, g, need_dx=(lvl > 0), red=red)
         ctx.saved = None
         return (None,) * n_in

@@ -394,3 +394,38 @@ def test_flat_adamw_matches_torch_adamw():
         oa.zero_grad(); ob.zero_grad()
     for (n, p), q in zip(a.named_parameters(), b.parameters()):
         assert float((p - q).abs().max()) < 2e-6, n
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,sp,N", [(32, 32, (32, 32, 32), 2), (64, 32, (12, 12, 12), 2), (16, 48, (6, 6, 6), 1)])
+def test_conv_dgrad_fused_instnorm_backward_reductions(dtype, cin, cout, sp, N):
+    """da = dgrad(dy) with the InstanceNorm-backward reductions of the receiving layer fused in the epilogue ==
+    separate dgrad + msseg_instnorm_act_bwd_reduce"""
+    from medicalsemseg_amd import hip
+    from medicalsemseg_amd.layers import Conv3, InstNormAct
+    dev = _dev()
+    # layer L: yraw_L [cin ch] -> act_L ; layer L+1: conv cin -> cout ; dy = grad of conv output
+    yraw = cl(gen(N, cin, *sp, seed=1) * 1.5 + 0.3, dtype, dev)
+    w = torch.nn.Parameter(gen(cout, cin, 3, 3, 3, seed=2, scale=(cin * 27) ** -0.5).to(dev))
+    dy = cl(gen(N, cout, *sp, seed=3), dtype, dev)
+    ga = torch.nn.Parameter((gen(cin, seed=4) * 0.2 + 1).to(dev))
+    be = torch.nn.Parameter((gen(cin, seed=5) * 0.2).to(dev))
+    nrm = InstNormAct(ga, be, 0.1)
+    act, stats = nrm.fwd(yraw)
+    conv = Conv3(w, None)
+    w.requires_grad_(False)
+    # separate path
+    da_ref = conv.bwd(act, dy, True)
+    dyraw_ref = nrm.bwd(yraw, stats, act, da_ref)
+    g_ref, b_ref = ga.grad.clone(), be.grad.clone()
+    ga.grad = be.grad = None
+    # fused path
+    da, red = conv.bwd(act, dy, True, next_norm=(nrm, yraw, stats, act))
+    assert red is not None
+    dyraw = nrm.bwd(yraw, stats, act, da, red=red)
+    assert torch.equal(da, da_ref)
+    tol = 2e-4 if dtype == torch.float32 else 2e-3
+    sc = float(dyraw_ref.float().abs().max())
+    assert float((dyraw.float() - dyraw_ref.float()).abs().max()) / sc < tol
+    for a, b, nm in ((ga.grad, g_ref, "dgamma"), (be.grad, b_ref, "dbeta")):
+        assert float((a - b).abs().max()) / (float(b.abs().max()) + 1e-6) < 5e-4, nm
