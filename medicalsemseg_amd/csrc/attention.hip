@@ -7,43 +7,13 @@
 // mask from coordinates, and streams keys through LDS with an online softmax, so the [B_,h,N,N] score tensor
 // never exists.  This is the exact-fp32-math version used for both dtypes (bf16 I/O, fp32 accumulate); one
 // workgroup = one window, one thread = one query (forward / dQ) or one key (dK, dV).
-#include "common.h"
+#include "attention_common.h"
+
+#include <stdlib.h>
+
+using namespace msseg_attn;
 
 namespace {
-
-struct AttnParams {
-    const void* qkv;      // [B, S, H, W, 3C]  channel = which*C + head*hd + e
-    const float* qkv_bias;  // [3C] or null (value of padded tokens)
-    const float* table;   // relative position bias table [(2ws-1)^3][heads]
-    void* out;            // [B, S, H, W, C]
-    float* lse;           // [B, nW, heads, N]   log-sum-exp per query (saved for backward)
-    const void* dout;     // backward: [B,S,H,W,C]
-    void* dqkv;           // backward: [B,S,H,W,3C]
-    float* dtable;        // backward: [(2ws-1)^3][heads] fp32, accumulated (atomics from per-workgroup LDS sums)
-    int dtab_all_heads;   // the workgroup keeps dtable partial sums for all heads in LDS across its windows
-    int B, S, H, W, C, heads, hd, ws, shift;
-    int Sp, Hp, Wp, nWs, nWh, nWw, N, M3, nwin_total;
-    float scale;
-    int use_mask;
-};
-
-MSSEG_DEVFN int region_id(int z, int Lp, int ws, int shift) { return z < Lp - ws ? 0 : (z < Lp - shift ? 1 : 2); }
-
-// token of window (wz,wy,wx) position p: returns linear voxel index in [0, S*H*W) or -1 for a padded token;
-// reg = region id triple packed (only meaningful when shift > 0)
-MSSEG_DEVFN int window_token(const AttnParams& p, int wz, int wy, int wx, int pos, int& reg, int& code) {
-    const int ws = p.ws;
-    const int pz = pos / (ws * ws), py = (pos / ws) % ws, px = pos % ws;
-    code = (pz * (2 * ws - 1) + py) * (2 * ws - 1) + px;  // rel_index(i, j) = code_i - code_j + off
-    const int sz = wz * ws + pz, sy = wy * ws + py, sx = wx * ws + px;  // coordinates in the shifted, padded grid
-    reg = region_id(sz, p.Sp, ws, p.shift) * 9 + region_id(sy, p.Hp, ws, p.shift) * 3 + region_id(sx, p.Wp, ws, p.shift);
-    int z = sz + p.shift, y = sy + p.shift, x = sx + p.shift;      // shifted[i] = x[(i + shift) mod Lp]
-    if (z >= p.Sp) z -= p.Sp;
-    if (y >= p.Hp) y -= p.Hp;
-    if (x >= p.Wp) x -= p.Wp;
-    if (z >= p.S || y >= p.H || x >= p.W) return -1;
-    return (z * p.H + y) * p.W + x;
-}
 
 constexpr int HD_MAX = 32;
 
@@ -400,6 +370,10 @@ int msseg_window_attention_fwd(const void* qkv, const float* qkv_bias, const flo
     p.qkv = qkv; p.qkv_bias = qkv_bias; p.table = table; p.out = out; p.lse = lse;
     const size_t smem = (size_t)p.N * p.hd * 2 * 4 + (size_t)p.M3 * 4 + (size_t)p.N * 3 * 4;
     if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd: window too large for LDS");
+    if (dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 224 && (C % 8) == 0 && !getenv("MSSEG_ATTN_NO_MFMA")) {
+        // bf16: QK^T and PV on the matrix cores (attention_mfma.hip)
+        return msseg_window_attention_fwd_mfma(p, (hipStream_t)stream);
+    }
     if (dtype == MSSEG_F32) ATTN_LAUNCH(win_attn_fwd_kernel, float, smem);
     else if (dtype == MSSEG_BF16) ATTN_LAUNCH(win_attn_fwd_kernel, bf16_t, smem);
     else MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd: bad dtype");

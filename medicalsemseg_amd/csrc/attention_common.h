@@ -1,0 +1,44 @@
+// shared by attention.hip (exact-fp32-math kernels) and attention_mfma.hip (bf16 MFMA forward)
+#pragma once
+#include "common.h"
+
+namespace msseg_attn {
+
+struct AttnParams {
+    const void* qkv;      // [B, S, H, W, 3C]  channel = which*C + head*hd + e
+    const float* qkv_bias;  // [3C] or null (value of padded tokens)
+    const float* table;   // relative position bias table [(2ws-1)^3][heads]
+    void* out;            // [B, S, H, W, C]
+    float* lse;           // [B, nW, heads, N]   log-sum-exp per query (saved for backward)
+    const void* dout;     // backward: [B,S,H,W,C]
+    void* dqkv;           // backward: [B,S,H,W,3C]
+    float* dtable;        // backward: [(2ws-1)^3][heads] fp32, accumulated (atomics from per-workgroup LDS sums)
+    int dtab_all_heads;   // the workgroup keeps dtable partial sums for all heads in LDS across its windows
+    int B, S, H, W, C, heads, hd, ws, shift;
+    int Sp, Hp, Wp, nWs, nWh, nWw, N, M3, nwin_total;
+    float scale;
+    int use_mask;
+};
+
+MSSEG_DEVFN int region_id(int z, int Lp, int ws, int shift) { return z < Lp - ws ? 0 : (z < Lp - shift ? 1 : 2); }
+
+// token of window (wz,wy,wx) position p: returns linear voxel index in [0, S*H*W) or -1 for a padded token;
+// reg = region id triple packed (only meaningful when shift > 0)
+MSSEG_DEVFN int window_token(const AttnParams& p, int wz, int wy, int wx, int pos, int& reg, int& code) {
+    const int ws = p.ws;
+    const int pz = pos / (ws * ws), py = (pos / ws) % ws, px = pos % ws;
+    code = (pz * (2 * ws - 1) + py) * (2 * ws - 1) + px;  // rel_index(i, j) = code_i - code_j + off
+    const int sz = wz * ws + pz, sy = wy * ws + py, sx = wx * ws + px;  // coordinates in the shifted, padded grid
+    reg = region_id(sz, p.Sp, ws, p.shift) * 9 + region_id(sy, p.Hp, ws, p.shift) * 3 + region_id(sx, p.Wp, ws, p.shift);
+    int z = sz + p.shift, y = sy + p.shift, x = sx + p.shift;      // shifted[i] = x[(i + shift) mod Lp]
+    if (z >= p.Sp) z -= p.Sp;
+    if (y >= p.Hp) y -= p.Hp;
+    if (x >= p.Wp) x -= p.Wp;
+    if (z >= p.S || y >= p.H || x >= p.W) return -1;
+    return (z * p.H + y) * p.W + x;
+}
+
+
+}  // namespace msseg_attn
+
+int msseg_window_attention_fwd_mfma(const msseg_attn::AttnParams& p, hipStream_t stream);  // attention_mfma.hip

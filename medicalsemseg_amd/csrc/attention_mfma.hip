@@ -1,0 +1,189 @@
+// Swin 3-D window attention forward on the matrix cores (bf16): S^T = K Q^T and O^T = V^T P with
+// v_mfma_f32_32x32x16_bf16, softmax in registers.
+//
+// One workgroup (4 waves) = one window; heads are looped; a wave owns 32-query tiles.  For a query tile the wave
+// computes the TRANSPOSED score tile X_j = K_j Q_i^T for every 32-key tile j (A = K rows, B = Q rows, both read from
+// row-major LDS images with ds_read_b128).  An accumulator of that MFMA has the query on the lane and the keys in
+// its 16 registers, so (1) the softmax over keys is a per-lane reduction over registers plus one exchange with lane
+// l^32, and (2) the probabilities, converted pairwise to bf16, ARE the B operand of the next MFMA O^T += V^T_j P_j
+// with no lane movement (cdna_hip_programming.md section 3, "an accumulator tile as the next MFMA's operand";
+// the A operand V^T is read from a transposed LDS image with the matching permuted key order).
+// Relative-position bias comes from the per-head table in LDS via code_q - code_k, the shifted-window -100 mask from
+// region ids, padded keys (N..32*NKT) get -inf.  Same addressing / padded-token semantics as attention.hip.
+#include "attention_common.h"
+
+using namespace msseg_attn;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <int HD, int NKT>
+__global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const AttnParams p) {
+    constexpr int NP = NKT * 32;          // padded token count
+    constexpr int KS = HD / 16;           // 32x32x16 k-steps over the head dim
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* qS = (bf16_t*)smem;                    // [NP][HD]
+    bf16_t* kS = qS + NP * HD;                     // [NP][HD]
+    bf16_t* vT = kS + NP * HD;                     // [HD][NP]   (transposed)
+    float* tabS = (float*)(vT + HD * NP);          // [M3]
+    int* tok = (int*)(tabS + p.M3);                // [NP]
+    unsigned short* kinfo = (unsigned short*)(tok + NP);  // [NP]  code | region << 11 ; 0xFFFF = padded key
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int nW = p.nWs * p.nWh * p.nWw;
+    const int m = 2 * p.ws - 1;
+    const int off = ((p.ws - 1) * m + (p.ws - 1)) * m + (p.ws - 1);
+    const int C3 = 3 * p.C;
+
+    for (int wb = blockIdx.x; wb < p.nwin_total; wb += gridDim.x) {
+        const int w = wb % nW, b = wb / nW;
+        const int wx = w % p.nWw, wy = (w / p.nWw) % p.nWh, wz = w / (p.nWw * p.nWh);
+        const bf16_t* qkv = (const bf16_t*)p.qkv + (long long)b * p.S * p.H * p.W * C3;
+        bf16_t* out = (bf16_t*)p.out + (long long)b * p.S * p.H * p.W * p.C;
+        __syncthreads();
+        for (int i = tid; i < NP; i += 256) {
+            if (i < p.N) {
+                int rg, cd;
+                tok[i] = window_token(p, wz, wy, wx, i, rg, cd);
+                kinfo[i] = (unsigned short)(cd | (rg << 11));
+            } else {
+                tok[i] = -2;            // padded row of the MFMA tile (not a token)
+                kinfo[i] = 0xFFFF;
+            }
+        }
+        for (int h = 0; h < p.heads; ++h) {
+            __syncthreads();
+            for (int i = tid; i < p.M3; i += 256) tabS[i] = p.table[(long long)i * p.heads + h];
+            // stage Q, K (row-major) and V (transposed): one 16-byte chunk (8 channels) per thread-iteration
+            constexpr int CPT = HD / 8;   // chunks per token per matrix
+            for (int i = tid; i < NP * CPT * 3; i += 256) {
+                const int which = i / (NP * CPT), rem = i % (NP * CPT);
+                const int t = rem / CPT, ch = rem % CPT;
+                const int tk = tok[t];
+                bf16x8_t v;
+                if (tk >= 0) {
+                    v = *(const bf16x8_t*)(qkv + (long long)tk * C3 + which * p.C + h * HD + ch * 8);
+                } else if (tk == -1 && p.qkv_bias) {   // spatially padded token: Linear(0) = bias
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)p.qkv_bias[which * p.C + h * HD + ch * 8 + e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+                }
+                if (which == 0) *(bf16x8_t*)(qS + t * HD + ch * 8) = v;
+                else if (which == 1) *(bf16x8_t*)(kS + t * HD + ch * 8) = v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vT[(ch * 8 + e) * NP + t] = v[e];
+                }
+            }
+            __syncthreads();
+            for (int qt = wave; qt < NKT; qt += 4) {
+                const int qi = qt * 32 + r;              // this lane's query (column of every X tile)
+                const unsigned short qinfo = kinfo[qi];
+                const int qcode = (qinfo == 0xFFFF ? 0 : (qinfo & 2047)) + off, qreg = qinfo >> 11;  // padded query rows: any valid code
+                // ---- X_j = K_j Q_i^T ----
+                bf16x8_t qf[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) qf[s] = *(const bf16x8_t*)(qS + qi * HD + s * 16 + hh * 8);
+                f32x16_t X[NKT];
+#pragma unroll
+                for (int j = 0; j < NKT; ++j) {
+                    f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const bf16x8_t kf = *(const bf16x8_t*)(kS + (j * 32 + r) * HD + s * 16 + hh * 8);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], acc, 0, 0, 0);
+                    }
+                    X[j] = acc;
+                }
+                // ---- scores: scale, relative-position bias, shift mask, key padding; row max ----
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const int key = j * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                        const unsigned short ki = kinfo[key];
+                        float sc;
+                        if (ki == 0xFFFF) sc = -INFINITY;
+                        else {
+                            sc = X[j][g] * p.scale + tabS[qcode - (ki & 2047)];
+                            if (p.use_mask && (ki >> 11) != qreg) sc += -100.f;
+                        }
+                        X[j][g] = sc;
+                        mx = fmaxf(mx, sc);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float l = 0.f;
+#pragma unroll
+                for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const float pe = __expf(X[j][g] - mx);
+                        X[j][g] = pe;
+                        l += pe;
+                    }
+                l += __shfl_xor(l, 32);
+                // ---- O^T += V^T_j P_j  (P_j straight from the accumulator registers) ----
+                f32x16_t Y = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const int vrow = r & (HD - 1);   // rows >= HD of the 32-row A tile are don't-care
+#pragma unroll
+                for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        bf16x8_t pf;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)X[j][8 * s + e];
+                        // element e of lane-half hh of P's fragment is key row 16s + 8(e>>2) + 4hh + (e&3) of tile j
+                        const bf16_t* vp = vT + vrow * NP + j * 32 + 16 * s + 4 * hh;
+                        const bf16x4_t v0 = *(const bf16x4_t*)vp;
+                        const bf16x4_t v1 = *(const bf16x4_t*)(vp + 8);
+                        const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, Y, 0, 0, 0);
+                    }
+                // ---- store: lane = query, registers = head-dim rows (reg&3) + 8*(reg>>2) + 4*hh ----
+                const int tk = tok[qi];
+                const float inv = 1.f / l;
+                if (qi < p.N) {
+                    if (hh == 0) p.lse[((long long)wb * p.heads + h) * p.N + qi] = mx + __logf(l);
+                    if (tk >= 0) {
+                        bf16_t* orow = out + (long long)tk * p.C + h * HD;
+#pragma unroll
+                        for (int g4 = 0; g4 < HD / 8; ++g4) {
+                            bf16x4_t o = {(bf16_t)(Y[4 * g4 + 0] * inv), (bf16_t)(Y[4 * g4 + 1] * inv),
+                                          (bf16_t)(Y[4 * g4 + 2] * inv), (bf16_t)(Y[4 * g4 + 3] * inv)};
+                            *(bf16x4_t*)(orow + 8 * g4 + 4 * hh) = o;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int HD, int NKT> int launch(const AttnParams& p, hipStream_t stream) {
+    constexpr int NP = NKT * 32;
+    const size_t smem = (size_t)3 * NP * HD * 2 + (size_t)p.M3 * 4 + (size_t)NP * 4 + (size_t)NP * 2 + 16;
+    int gx = p.nwin_total < msseg_num_cus() * 4 ? p.nwin_total : msseg_num_cus() * 4;
+    hipLaunchKernelGGL((win_attn_fwd_mfma_kernel<HD, NKT>), dim3(gx), dim3(256), smem, stream, p);
+    MSSEG_CHECK_LAUNCH("window_attention_fwd_mfma");
+    return MSSEG_OK;
+}
+
+template <int HD> int launch_hd(const AttnParams& p, hipStream_t stream) {
+    const int nkt = (p.N + 31) / 32;
+    if (nkt == 1) return launch<HD, 1>(p, stream);
+    if (nkt == 2) return launch<HD, 2>(p, stream);
+    if (nkt <= 4) return launch<HD, 4>(p, stream);
+    return launch<HD, 7>(p, stream);
+}
+
+}  // namespace
+
+int msseg_window_attention_fwd_mfma(const AttnParams& p, hipStream_t stream) {
+    if (p.M3 > 2047 || p.N > 224) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd_mfma: window too large");
+    return p.hd == 16 ? launch_hd<16>(p, stream) : launch_hd<32>(p, stream);
+}
