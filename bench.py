@@ -77,6 +77,41 @@ def cpu_baseline(batch, size, n_cls, budget_s=25.0):
                       f"step, oracle/ BasicUNet fp32 on torch-CPU, median {med:.2f} s/step"}
 
 
+def bench_sliding_window(args, dev, dtype, world, rank):
+    """512^3 sliding-window inference (roi 96^3, overlap 0.5, gaussian; 1000 windows) with the UNet in eval mode"""
+    from medicalsemseg_amd import parallel
+    from medicalsemseg_amd.engine.utils import sliding_window_inference
+    from medicalsemseg_amd.models.unet import UNet
+    net = UNet(1, args.classes, compute_dtype=dtype).to(dev).eval()
+    g = torch.Generator().manual_seed(13)
+    vol = torch.randn(1, 1, args.sw_size, args.sw_size, args.sw_size, generator=g).to(dev)
+    aff = torch.ones(1, 3, device=dev)
+
+    def run():
+        with torch.no_grad():
+            return sliding_window_inference(vol, aff, (args.size,) * 3, args.sw_batch, net, overlap=0.5, mode="gaussian")
+    for _ in range(max(args.warmup, 1)):
+        out = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": f"{args.sw_size}^3 sliding-window vols/sec", "value": round(args.steps / dt, 4),
+                          "unit": "vol/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "config": {"workload": f"UNet base 1->{args.classes}, {args.sw_size}^3 volume, roi {args.size}^3, "
+                                                 f"overlap 0.5, gaussian, sw_batch {args.sw_batch}", "parallelism": f"windows/{world}",
+                                     "out_mean": round(float(out.mean()), 5)}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +123,10 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
+    ap.add_argument("--workload", default="unet", choices=["unet", "swin_unetr", "sliding_window"],
+                    help="unet = the headline (BASELINE configs[1]); swin_unetr = configs[3]; sliding_window = configs[4]")
+    ap.add_argument("--sw-size", type=int, default=512)
+    ap.add_argument("--sw-batch", type=int, default=4)
     args = ap.parse_args()
 
     from medicalsemseg_amd import hip, parallel
@@ -106,7 +145,16 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(13 + rank)
-    net = UNet(1, args.classes, compute_dtype=dtype).to(dev)
+    if args.workload == "sliding_window":
+        return bench_sliding_window(args, dev, dtype, world, rank)
+    if args.workload == "swin_unetr":
+        from medicalsemseg_amd.models.swin_unetr import SwinTransformerNNFormer, SwinUNETRCustom
+        enc = SwinTransformerNNFormer((args.size,) * 3, (2, 2, 2), 1, 48, (2, 2, 2, 2), (3, 6, 12, 24), (6, 6, 6, 3),
+                                      drop_path_rate=0.0, compute_dtype=dtype)
+        net = SwinUNETRCustom(enc, 1, args.classes, (args.size,) * 3, 48, (2, 2, 2), compute_dtype=dtype).to(dev)
+        args.no_graph = True
+    else:
+        net = UNet(1, args.classes, compute_dtype=dtype).to(dev)
     opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=4e-4, betas=(0.9, 0.95), eps=1e-6)
     crit = DiceCELoss(smooth_nr=1e-5, smooth_dr=1e-5)
     x, y = synth_batch(args.batch, args.size, args.classes, dev, 13 + rank)
@@ -181,7 +229,9 @@ def main():
     vols = args.batch * args.steps * world
     value = vols / dt
     res = {
-        "metric": "96^3 vols/sec fwd+bwd (train)", "value": round(value, 3), "unit": "vol/s", "n_gpus": world,
+        "metric": "96^3 vols/sec fwd+bwd (train)" if args.workload == "unet" else
+                  "96^3 vols/sec fwd+bwd (train), Swin-UNETR-48 (reference encoder, window 6/6/6/3)",
+        "value": round(value, 3), "unit": "vol/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "launch": "hipGraph replay" if graph is not None else "eager",
