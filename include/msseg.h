@@ -181,10 +181,14 @@ int msseg_window_attention_bwd(const void* qkv, const float* qkv_bias, const flo
 /* LayerNorm over the channel dim of rows x C (nn.LayerNorm, eps 1e-5); mean/rstd [rows] saved for backward. */
 int msseg_layernorm_fwd(const void* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
                         float* mean, float* rstd, long long rows, int C, float eps, int dtype, msseg_stream_t stream);
-/* dgamma/dbeta (nullable, both or none) are ACCUMULATED. */
+/* input gradient */
 int msseg_layernorm_bwd(const void* x, long long ldx, const float* gamma, const float* mean, const float* rstd,
-                        const void* dy, long long lddy, void* dx, long long lddx, float* dgamma, float* dbeta,
-                        long long rows, int C, int dtype, msseg_stream_t stream);
+                        const void* dy, long long lddy, void* dx, long long lddx, long long rows, int C, int dtype,
+                        msseg_stream_t stream);
+/* parameter gradients dgamma[c] (+)= sum_rows dy*xhat, dbeta[c] (+)= sum_rows dy (deterministic two-stage reduction) */
+int msseg_layernorm_param_grad(const void* x, long long ldx, const float* mean, const float* rstd, const void* dy,
+                               long long lddy, float* dgamma, float* dbeta, int accumulate, long long rows, int C,
+                               void* scratch, size_t scratch_bytes, int dtype, msseg_stream_t stream);
 /* exact (erf) GELU */
 int msseg_gelu_fwd(const void* x, void* y, long long n, int dtype, msseg_stream_t stream);
 int msseg_gelu_bwd(const void* x, const void* dy, void* dx, long long n, int dtype, msseg_stream_t stream);

@@ -190,6 +190,91 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
         finalize_channels(ws, gridDim.y, gridDim.x, C, nacc, nacc == 2 ? 0 : 1, out, nullptr, nullptr, accumulate);
 }
 
+// LayerNorm parameter gradients: dgamma[c] = sum_rows dy*xhat, dbeta[c] = sum_rows dy  (xhat from per-row mean/rstd)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const T* __restrict__ x, long long ldx,
+                                                            const T* __restrict__ dy, long long lddy,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            long long rows, int C, int groups, int rows_par,
+                                                            long long rows_per_block, float* ws, unsigned int* counter,
+                                                            float* dgamma, float* dbeta, int accumulate) {
+    constexpr int W = VEC ? DT<T>::EPC : 1;
+    __shared__ float red[256 * 2 * (VEC ? DT<T>::EPC : 1)];
+    __shared__ int lflag;
+    const int g = threadIdx.x % groups, rl = threadIdx.x / groups;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float* wsb = ws + (long long)blockIdx.x * C * 2;
+    for (int gbase = 0; gbase * W < C; gbase += groups) {
+        const int gg = gbase + g;
+        const bool act = gg * W < C;
+        float s[W], s2[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) s[e] = s2[e] = 0.f;
+        if (act && rl < rows_par) {
+#pragma unroll 4
+            for (long long r = r0 + rl; r < r1; r += rows_par) {
+                const float mu = mean[r], rs = rstd[r];
+                if constexpr (VEC) {
+                    Chunk<T> cx, cd;
+                    cx.load(x + r * ldx + gg * W);
+                    cd.load(dy + r * lddy + gg * W);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) { s[e] += cd.v[e] * (cx.v[e] - mu) * rs; s2[e] += cd.v[e]; }
+                } else {
+                    const float d = DT<T>::ld(dy + r * lddy + gg);
+                    s[0] += d * (DT<T>::ld(x + r * ldx + gg) - mu) * rs;
+                    s2[0] += d;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            red[(threadIdx.x * W + e) * 2 + 0] = s[e];
+            red[(threadIdx.x * W + e) * 2 + 1] = s2[e];
+        }
+        __syncthreads();
+        if (act && rl == 0) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                float a = 0.f, b = 0.f;
+                for (int k = 0; k < rows_par; ++k) {
+                    a += red[((k * groups + g) * W + e) * 2 + 0];
+                    b += red[((k * groups + g) * W + e) * 2 + 1];
+                }
+                wsb[(gg * W + e) * 2 + 0] = a;
+                wsb[(gg * W + e) * 2 + 1] = b;
+            }
+        }
+    }
+    if (grid_last_block(counter, gridDim.x, &lflag))
+        finalize_channels(ws, 1, gridDim.x, C, 2, 2, ws + (long long)gridDim.x * C * 2, dgamma, dbeta, accumulate);
+}
+
+inline long long reduce_blocks(long long S, int rows_par, int N, int C, int nper);
+
+template <typename T>
+int launch_ln_param_grad(const void* x, long long ldx, const void* dy, long long lddy, const float* mean, const float* rstd,
+                         float* dgamma, float* dbeta, int accumulate, long long rows, int C, void* scratch, hipStream_t st) {
+    const bool vec = vec_ok(x, ldx, C, sizeof(T)) && vec_ok(dy, lddy, C, sizeof(T));
+    const RowMap m = row_map(C, vec ? DT<T>::EPC : 1);
+    long long blocks = reduce_blocks(rows, m.rows_par, 1, C, 2);
+    const long long rpb = ceil_div_ll(rows, blocks);
+    blocks = ceil_div_ll(rows, rpb);
+    unsigned int* counter = (unsigned int*)scratch;
+    float* ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+    if (vec)
+        hipLaunchKernelGGL((ln_param_grad_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, ldx,
+                           (const T*)dy, lddy, mean, rstd, rows, C, m.groups, m.rows_par, rpb, ws, counter, dgamma, dbeta, accumulate);
+    else
+        hipLaunchKernelGGL((ln_param_grad_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, ldx,
+                           (const T*)dy, lddy, mean, rstd, rows, C, m.groups, m.rows_par, rpb, ws, counter, dgamma, dbeta, accumulate);
+    MSSEG_CHECK_LAUNCH("ln_param_grad");
+    return MSSEG_OK;
+}
+
 inline long long reduce_blocks(long long S, int rows_par, int N, int C, int nper) {
     // one block per CU in total (each keeps ~32 KB of loads in flight) keeps the finalising block's job small
     long long blocks = ceil_div_ll(S, (long long)rows_par * 8);
@@ -652,6 +737,17 @@ static int scratch_ok(const void* scratch, size_t bytes, const char* who) {
         MSSEG_FAIL(MSSEG_EWORKSPACE, "%s: needs a zero-initialised, 256-byte aligned scratch of %zu bytes", who,
                    msseg_reduce_scratch_bytes());
     return MSSEG_OK;
+}
+
+int msseg_layernorm_param_grad(const void* x, long long ldx, const float* mean, const float* rstd, const void* dy,
+                               long long lddy, float* dgamma, float* dbeta, int accumulate, long long rows, int C,
+                               void* scratch, size_t scratch_bytes, int dtype, msseg_stream_t stream) {
+    if (!x || !mean || !rstd || !dy || !dgamma || !dbeta || rows < 1 || C < 1)
+        MSSEG_FAIL(MSSEG_EINVAL, "layernorm_param_grad: bad args");
+    if (int rc = scratch_ok(scratch, scratch_bytes, "layernorm_param_grad")) return rc;
+    DISPATCH_T(dtype,
+               return launch_ln_param_grad<float>(x, ldx, dy, lddy, mean, rstd, dgamma, dbeta, accumulate, rows, C, scratch, (hipStream_t)stream),
+               return launch_ln_param_grad<bf16_t>(x, ldx, dy, lddy, mean, rstd, dgamma, dbeta, accumulate, rows, C, scratch, (hipStream_t)stream));
 }
 
 int msseg_channel_stats(const void* x, long long ldx, float* stats, int N, long long S, int C, void* scratch,

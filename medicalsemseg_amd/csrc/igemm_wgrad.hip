@@ -11,6 +11,8 @@
 // torch-layout gradient.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 enum { Q_DIRECT = 0, Q_GATHER = 1, Q_DECONV = 2 };
@@ -40,7 +42,9 @@ template <typename T, int NTAPS, int TD, int TH, int TW> struct WgCfg {
     static constexpr int PD = TD + 2 * PAD, PH = TH + 2 * PAD, PW = TW + 2 * PAD;
     static constexpr int HV = PD * PH * PW;
     static constexpr int TV = TD * TH * TW;
-    static constexpr int RS = 64 + (ESZ == 2 ? 32 : 0);  // LDS row stride in bytes (bf16 rows padded: tr-read banks)
+    // LDS row stride in bytes.  bf16 rows are padded to 96 B (conflict-free transposing reads) when the tile then
+    // still fits; the 2x8x16 tile keeps 64-B rows so that TWO workgroups share a CU (62 KB each).
+    static constexpr int RS = 64 + ((ESZ == 2 && !(TD == 2 && TH == 8 && TW == 16)) ? 32 : 0);
     static constexpr int P_BYTES = ((TV * RS + 255) / 256) * 256;
     static constexpr int Q_BYTES = ((HV * RS + 255) / 256) * 256;
     static constexpr int LDS_BYTES = P_BYTES + Q_BYTES;
@@ -467,7 +471,11 @@ int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes
 
 template <typename T> int launch_wg_k3(WgradParams& p, ReduceParams& rp, void* ws, size_t wsb, hipStream_t st) {
     const int mn = p.D < p.H ? (p.D < p.W ? p.D : p.W) : (p.H < p.W ? p.H : p.W);
-    if (mn >= 32) return launch_wg<T, 27, Q_DIRECT, 4, 8, 16>(p, rp, ws, wsb, st);
+    if (mn >= 32) {
+        static const bool two_wg = getenv("MSSEG_WGRAD_2WG") != nullptr;   // A/B switch
+        if (two_wg) return launch_wg<T, 27, Q_DIRECT, 2, 8, 16>(p, rp, ws, wsb, st);
+        return launch_wg<T, 27, Q_DIRECT, 4, 8, 16>(p, rp, ws, wsb, st);
+    }
     if (mn >= 12) return launch_wg<T, 27, Q_DIRECT, 4, 4, 8>(p, rp, ws, wsb, st);
     return launch_wg<T, 27, Q_DIRECT, 2, 4, 8>(p, rp, ws, wsb, st);
 }

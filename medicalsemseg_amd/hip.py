@@ -41,7 +41,8 @@ SIGNATURES = {
     "msseg_window_attention_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_window_attention_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_layernorm_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _ll, _i, _f, _i, _vp], _i),
-    "msseg_layernorm_bwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _ll, _i, _i, _vp], _i),
+    "msseg_layernorm_bwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _vp], _i),
+    "msseg_layernorm_param_grad": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _i, _ll, _i, _vp, _sz, _i, _vp], _i),
     "msseg_gelu_fwd": ([_vp, _vp, _ll, _i, _vp], _i),
     "msseg_gelu_bwd": ([_vp, _vp, _vp, _ll, _i, _vp], _i),
     "msseg_conv3d_k1_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
@@ -639,7 +640,11 @@ def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma=None, dbeta=None):
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     _ck(lib().msseg_layernorm_bwd(_p(x), ld(x), _p(gamma), _p(mean), _p(rstd), _p(dy), ld(dy), _p(dx), ld(dx),
-                                  _p(dgamma), _p(dbeta), rows, Cc, dt(x), _stream()), "layernorm_bwd")
+                                  rows, Cc, dt(x), _stream()), "layernorm_bwd")
+    if dgamma is not None:
+        sc = scratch(x.device)
+        _ck(lib().msseg_layernorm_param_grad(_p(x), ld(x), _p(mean), _p(rstd), _p(dy), ld(dy), _p(dgamma), _p(dbeta), 0,
+                                             rows, Cc, _p(sc), sc.numel(), dt(x), _stream()), "layernorm_param_grad")
     return dx
 
 

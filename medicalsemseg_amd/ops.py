@@ -64,8 +64,8 @@ class LayerNormFn(torch.autograd.Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         dy = _c(dy)
         dx = torch.empty_like(x)
-        dg = torch.zeros_like(gamma) if ctx.needs_input_grad[1] else None
-        db = torch.zeros_like(gamma) if ctx.needs_input_grad[1] else None
+        dg = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
+        db = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
         hip.layernorm_bwd(x, gamma, mean, rstd, dy, dx, dg, db)
         return dx, dg, db, None
 
