@@ -73,11 +73,11 @@ struct RowMap {
     int groups;       // channel groups per voxel
     int rows_par;     // voxel rows processed in parallel by a block
 };
-inline RowMap row_map(int C, int width) {
+inline RowMap row_map(int C, int width, int nthr = 256) {
     RowMap m;
     m.groups = ceil_div(C, width);
-    if (m.groups > 256) m.groups = 256;
-    m.rows_par = 256 / m.groups;
+    if (m.groups > nthr) m.groups = nthr;
+    m.rows_par = nthr / m.groups;
     if (m.rows_par < 1) m.rows_par = 1;
     return m;
 }
@@ -97,9 +97,10 @@ MSSEG_DEVFN void finalize_channels(const float* ws, int N, int nblk, int C, int 
     const int cols = L < 256 ? L : 256;
     const int G = 256 / cols;               // row groups
     const int col = threadIdx.x % cols, rg = threadIdx.x / cols;
+    const bool in256 = threadIdx.x < 256;   // blocks may be larger than the 256 threads this routine tiles
     for (int c0 = 0; c0 < L; c0 += cols) {
         const int o = c0 + col;
-        const bool ok = o < L && rg < G;
+        const bool ok = in256 && o < L && rg < G;
         float tot = 0.f;
         for (int n = 0; n < N; ++n) {
             float s = 0.f;
@@ -109,7 +110,7 @@ MSSEG_DEVFN void finalize_channels(const float* ws, int N, int nblk, int C, int 
                 for (int bb = rg; bb < nblk; bb += G) s += src[(long long)bb * L];
             }
             __syncthreads();
-            fin[threadIdx.x] = s;
+            if (in256) fin[threadIdx.x] = s;
             __syncthreads();
             if (ok && rg == 0) {
                 float t = 0.f;
@@ -130,13 +131,36 @@ MSSEG_DEVFN void finalize_channels(const float* ws, int N, int nblk, int C, int 
     }
 }
 
+// Reduction kernels run 512-thread blocks (8 waves per CU, one block per CU, 12+ loads in flight per thread): enough loads in flight to stream HBM
+// while the number of partial rows the finalising block has to add stays at one per CU.
+constexpr int RED_THREADS = 512;
+constexpr int RED_STAGE2 = 16;
+
+// two-stage fixed-order sum over the rows_par row slots of red[(k * groups + g) * W + e][2]; result in slot k = 0
+template <int W>
+MSSEG_DEVFN void block_rows_reduce(float* red, int groups, int rows_par, int g, int rl, bool act) {
+    if (act && rl < RED_STAGE2 && rl < rows_par) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float a = 0.f, b = 0.f;
+            for (int k = rl; k < rows_par; k += RED_STAGE2) {
+                a += red[((k * groups + g) * W + e) * 2 + 0];
+                b += red[((k * groups + g) * W + e) * 2 + 1];
+            }
+            red[((rl * groups + g) * W + e) * 2 + 0] = a;
+            red[((rl * groups + g) * W + e) * 2 + 1] = b;
+        }
+    }
+    __syncthreads();
+}
+
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, long long ldx, float* out,
+__global__ __launch_bounds__(RED_THREADS) void channel_stats_kernel(const T* __restrict__ x, long long ldx, float* out,
                                                             long long S, int C, int groups, int rows_par,
                                                             long long rows_per_block, int nacc, int accumulate,
                                                             float* ws, unsigned int* counter) {
     constexpr int W = VEC ? DT<T>::EPC : 1;
-    __shared__ float red[256 * 2 * (VEC ? DT<T>::EPC : 1)];
+    __shared__ float red[RED_THREADS * 2 * (VEC ? DT<T>::EPC : 1)];
     __shared__ int lflag;
     const int n = blockIdx.y;
     const int g = threadIdx.x % groups, rl = threadIdx.x / groups;
@@ -172,11 +196,13 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
             red[(threadIdx.x * W + e) * 2 + 1] = s2[e];
         }
         __syncthreads();
+        block_rows_reduce<W>(red, groups, rows_par, g, rl, act);
         if (act && rl == 0) {
+            const int kmax = rows_par < RED_STAGE2 ? rows_par : RED_STAGE2;
 #pragma unroll
             for (int e = 0; e < W; ++e) {
                 float a = 0.f, b = 0.f;
-                for (int k = 0; k < rows_par; ++k) {
+                for (int k = 0; k < kmax; ++k) {
                     a += red[((k * groups + g) * W + e) * 2 + 0];
                     b += red[((k * groups + g) * W + e) * 2 + 1];
                 }
@@ -291,7 +317,7 @@ template <typename T>
 int launch_stats(const void* x, long long ldx, float* out, int N, long long S, int C, int nacc, int accumulate,
                  void* scratch, hipStream_t st) {
     const bool vec = vec_ok(x, ldx, C, sizeof(T));
-    const RowMap m = row_map(C, vec ? DT<T>::EPC : 1);
+    const RowMap m = row_map(C, vec ? DT<T>::EPC : 1, RED_THREADS);
     long long blocks = reduce_blocks(S, m.rows_par, N, C, nacc);
     const long long rpb = ceil_div_ll(S, blocks);
     blocks = ceil_div_ll(S, rpb);
@@ -299,10 +325,10 @@ int launch_stats(const void* x, long long ldx, float* out, int N, long long S, i
     unsigned int* counter = (unsigned int*)scratch;
     float* ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
     if (vec)
-        hipLaunchKernelGGL((channel_stats_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x, ldx, out, S, C,
+        hipLaunchKernelGGL((channel_stats_kernel<T, true>), grid, dim3(RED_THREADS), 0, st, (const T*)x, ldx, out, S, C,
                            m.groups, m.rows_par, rpb, nacc, accumulate, ws, counter);
     else
-        hipLaunchKernelGGL((channel_stats_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x, ldx, out, S, C,
+        hipLaunchKernelGGL((channel_stats_kernel<T, false>), grid, dim3(RED_THREADS), 0, st, (const T*)x, ldx, out, S, C,
                            m.groups, m.rows_par, rpb, nacc, accumulate, ws, counter);
     MSSEG_CHECK_LAUNCH("channel_stats");
     return MSSEG_OK;
@@ -336,9 +362,9 @@ MSSEG_DEVFN void mean_rstd(const float* stats, int n, int C, int c, long long S,
 
 // MODE 0: forward   MODE 1: backward reduce   MODE 2: backward apply
 template <typename T, bool VEC, int MODE>
-__global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
+__global__ __launch_bounds__(MODE == 1 ? RED_THREADS : 256) void instnorm_kernel(const NormParams p) {
     constexpr int W = VEC ? DT<T>::EPC : 1;
-    __shared__ float red[(MODE == 1) ? 256 * 2 * W : 1];
+    __shared__ float red[(MODE == 1) ? RED_THREADS * 2 * W : 1];
     __shared__ int lflag;
     const int n = blockIdx.y;
     const int g = threadIdx.x % p.groups, rl = threadIdx.x / p.groups;
@@ -457,11 +483,13 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
                 red[(threadIdx.x * W + e) * 2 + 1] = a1[e];
             }
             __syncthreads();
+            block_rows_reduce<W>(red, p.groups, p.rows_par, g, rl, act);
             if (act && rl == 0) {
+                const int kmax = p.rows_par < RED_STAGE2 ? p.rows_par : RED_STAGE2;
 #pragma unroll
                 for (int e = 0; e < W; ++e) {
                     float a = 0.f, b = 0.f;
-                    for (int k = 0; k < p.rows_par; ++k) {
+                    for (int k = 0; k < kmax; ++k) {
                         a += red[((k * p.groups + g) * W + e) * 2 + 0];
                         b += red[((k * p.groups + g) * W + e) * 2 + 1];
                     }
@@ -481,14 +509,24 @@ __global__ __launch_bounds__(256) void instnorm_kernel(const NormParams p) {
 }
 
 template <typename T, int MODE> int launch_norm(NormParams& p, int N, bool vec, hipStream_t st) {
-    const RowMap m = row_map(p.C, vec ? DT<T>::EPC : 1);
+    constexpr int NTHR = MODE == 1 ? RED_THREADS : 256;
+    const RowMap m = row_map(p.C, vec ? DT<T>::EPC : 1, NTHR);
     p.groups = m.groups; p.rows_par = m.rows_par;
-    long long blocks = reduce_blocks(p.S, m.rows_par, N, p.C, 2);
+    long long blocks;
+    if (MODE == 1) {
+        blocks = reduce_blocks(p.S, m.rows_par, N, p.C, 2);
+    } else {
+        // pure streaming passes: 8 blocks of 4 waves per CU, each thread with 4+ independent 16-byte loads in flight
+        blocks = ceil_div_ll(p.S, (long long)m.rows_par * 4);
+        const long long cap = (long long)msseg_num_cus() * 8 / (N > 0 ? N : 1);
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+    }
     p.rows_per_block = ceil_div_ll(p.S, blocks);
     blocks = ceil_div_ll(p.S, p.rows_per_block);
     dim3 grid((unsigned)blocks, N);
-    if (vec) hipLaunchKernelGGL((instnorm_kernel<T, true, MODE>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((instnorm_kernel<T, false, MODE>), grid, dim3(256), 0, st, p);
+    if (vec) hipLaunchKernelGGL((instnorm_kernel<T, true, MODE>), grid, dim3(NTHR), 0, st, p);
+    else hipLaunchKernelGGL((instnorm_kernel<T, false, MODE>), grid, dim3(NTHR), 0, st, p);
     MSSEG_CHECK_LAUNCH("instnorm");
     return MSSEG_OK;
 }

@@ -17,8 +17,11 @@
 // flipped weights), conv k1, few-channel convs gathered im2col-style (stem conv, patch embedding),
 // ConvTranspose k2 s2 forward (1x1 GEMM + pixel-shuffle scatter) and its input gradient (gather).
 #include "common.h"
+#include "k3pp.h"
 
 #include <stdlib.h>
+
+#include <type_traits>
 
 namespace {
 
@@ -84,12 +87,18 @@ struct IgemmCfg {
 
 MSSEG_DEVFN int aoff(int q, int plane) { return q * plane + (q >> 1) * 32; }
 
-template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1, int NSL = 1>
+// DIAG (timing-only ablations, wrong results): 1 = no MFMA, 2 = no LDS fragment reads, 3 = no epilogue stores,
+// 4 = no global prefetch loads
+// DIAG == 5: per-phase cycle counters of workgroup 0 / wave 0 (s_memtime), read back by msseg_debug_phase_cycles()
+__device__ unsigned long long g_phase_cycles[16];
+
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1, int NSL = 1, int DIAG = 0>
 __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kernel(const IgemmParams p) {
     using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE, NSL>;
     constexpr int BT = C::BT;
     constexpr int EPC = C::EPC, CB = C::CB, PAD = C::PAD, PH = C::PH, PW = C::PW, HV = C::HV, MT = C::MT;
     constexpr int NTHREADS = C::NTHREADS, COUTB = C::COUTB, PLANE = C::PLANE;
+    constexpr bool HREUSE = NTAPS == 27 && STRIDE == 1 && NSL == 1 && TW == 16 && TH % MT == 0 && DIAG != 1 && DIAG != 2;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     unsigned char* ldsA = smem;
     unsigned char* ldsB = smem + C::A_BYTES;
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
     // DIRECT source: the (halo voxel, chunk) a thread stages is the same for every tile, so its element offset
     // relative to the tile origin and its halo coordinates are computed once (VALU work per tile drops from ~40 to
     // ~3 instructions per chunk; interior tiles skip the bounds checks altogether).
-    int a_rel[NIT_A], a_pk[NIT_A];
+    int a_rel[NIT_A];
     const int XD = STRIDE == 1 ? p.D : p.ID, XH = STRIDE == 1 ? p.H : p.IH, XW = STRIDE == 1 ? p.W : p.IW;
     if constexpr (SRC == SRC_DIRECT) {
 #pragma unroll
@@ -234,64 +243,60 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
             const int cq = i & 3, hv = i >> 2;
             const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
             a_rel[it] = (int)((((long long)hd * XH + hh) * XW + hw) * p.ldx) + cq * EPC;
-            a_pk[it] = (i < HV * 4) ? (hd | (hh << 8) | (hw << 16)) : -1;
         }
     }
-    auto fetch = [&](const TileCo& tc, int kb, int ks, bool with_a, bool with_b) {
-        if (with_a) {
+    // The global loads of a stage are issued one at a time (fetch_a / fetch_b) from slots spread over the MFMA loop
+    // of the previous stage, after fetch_setup() has fixed the stage's base pointers.
+    const T* f_bp = xg;
+    const u32x4_t* f_bsrc = nullptr;
+    bool f_interior = false, f_cok = false;
+    int f_dB = 0, f_hB = 0, f_wB = 0, f_kb = 0;
+    TileCo f_tc{0, 0, 0, 0};
+    auto fetch_setup = [&](const TileCo& tc, int kb, int ks) {
+        f_tc = tc;
+        f_kb = kb;
+        if constexpr (SRC == SRC_DIRECT) {
+            f_dB = tc.d0 * STRIDE - PAD; f_hB = tc.h0 * STRIDE - PAD; f_wB = tc.w0 * STRIDE - PAD;
+            const long long basev = (((long long)tc.n * XD + f_dB) * XH + f_hB) * XW + f_wB;
+            f_bp = xg + basev * p.ldx + kb * CB;
+            f_interior = f_dB >= 0 && f_dB + C::PD <= XD && f_hB >= 0 && f_hB + PH <= XH && f_wB >= 0 && f_wB + PW <= XW;
+            const int nchunk = (p.K - kb * CB + EPC - 1) / EPC;   // valid 16-byte chunks of this channel block
+            f_cok = (tid & 3) < nchunk;
+        }
+        f_bsrc = (const u32x4_t*)((const unsigned char*)p.wp + (((long long)coutblk * p.NKB + kb) * NSL + ks) * C::B_BYTES);
+    };
+    auto fetch_a = [&](int it) {
+        if constexpr (DIAG == 4) { pa[it] = u32x4_t{1u, 2u, 3u, 4u}; return; }
+        const int i = tid + it * NTHREADS;
         if constexpr (SRC == SRC_DIRECT) {
             if (p.rel32_ok) {
-                const int dB = tc.d0 * STRIDE - PAD, hB = tc.h0 * STRIDE - PAD, wB = tc.w0 * STRIDE - PAD;
-                const long long basev = (((long long)tc.n * XD + dB) * XH + hB) * XW + wB;
-                const T* bp = xg + basev * p.ldx + kb * CB;
-                const bool interior = dB >= 0 && dB + C::PD <= XD && hB >= 0 && hB + PH <= XH && wB >= 0 && wB + PW <= XW;
-                const int nchunk = (p.K - kb * CB + EPC - 1) / EPC;   // valid 16-byte chunks of this channel block
-                const bool cok = (tid & 3) < nchunk;
-                if (interior) {
-#pragma unroll
-                    for (int it = 0; it < NIT_A; ++it) {
-                        const bool valid = (NSL > 1) ? (tid + it * NTHREADS < HV * 4) : (a_pk[it] >= 0);
-                        pa[it] = (cok && valid) ? *(const u32x4_t*)(bp + a_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
-                    }
-                } else {
-#pragma unroll
-                    for (int it = 0; it < NIT_A; ++it) {
-                        int pk = a_pk[it];
-                        if constexpr (NSL > 1) {   // register-lean variant: recompute the halo coordinates
-                            const int i = tid + it * NTHREADS;
-                            const int hv = i >> 2;
-                            const int hw = hv % PW, t2 = hv / PW;
-                            pk = (i < HV * 4) ? ((t2 / PH) | ((t2 % PH) << 8) | (hw << 16)) : -1;
-                        }
-                        const int d = dB + (pk & 255), h = hB + ((pk >> 8) & 255), w = wB + ((pk >> 16) & 255);
-                        const bool ok = cok && pk >= 0 && (unsigned)d < (unsigned)XD && (unsigned)h < (unsigned)XH &&
-                                        (unsigned)w < (unsigned)XW;
-                        pa[it] = ok ? *(const u32x4_t*)(bp + a_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
-                    }
+                bool ok = f_cok && i < HV * 4;
+                if (!f_interior) {   // edge tile: recompute this chunk's halo coordinates (kept out of registers)
+                    const int hv = i >> 2;
+                    const int hw = hv % PW, t2 = hv / PW;
+                    const int d = f_dB + t2 / PH, h = f_hB + t2 % PH, w = f_wB + hw;
+                    ok = ok && (unsigned)d < (unsigned)XD && (unsigned)h < (unsigned)XH && (unsigned)w < (unsigned)XW;
                 }
-            } else {
-#pragma unroll
-                for (int it = 0; it < NIT_A; ++it) {
-                    const int i = tid + it * NTHREADS;
-                    pa[it] = (i < HV * 4) ? load_a_chunk(tc, kb, i) : u32x4_t{0u, 0u, 0u, 0u};
-                }
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < NIT_A; ++it) {
-                const int i = tid + it * NTHREADS;
-                pa[it] = (i < HV * 4) ? load_a_chunk(tc, kb, i) : u32x4_t{0u, 0u, 0u, 0u};
+                pa[it] = ok ? *(const u32x4_t*)(f_bp + a_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
+                return;
             }
         }
+        pa[it] = (i < HV * 4) ? load_a_chunk(f_tc, f_kb, i) : u32x4_t{0u, 0u, 0u, 0u};
+    };
+    auto fetch_b = [&](int it) {
+        if constexpr (DIAG == 4) { pb[it] = u32x4_t{1u, 2u, 3u, 4u}; return; }
+        const int i = tid + it * NTHREADS;
+        pb[it] = (i < C::B_BYTES / 16) ? f_bsrc[i] : u32x4_t{0u, 0u, 0u, 0u};
+    };
+    auto fetch = [&](const TileCo& tc, int kb, int ks, bool with_a, bool with_b) {   // whole stage at once (prologue)
+        fetch_setup(tc, kb, ks);
+        if (with_a) {
+#pragma unroll
+            for (int it = 0; it < NIT_A; ++it) fetch_a(it);
         }
         if (with_b) {
-            const u32x4_t* src = (const u32x4_t*)((const unsigned char*)p.wp +
-                                                  (((long long)coutblk * p.NKB + kb) * NSL + ks) * C::B_BYTES);
 #pragma unroll
-            for (int it = 0; it < NIT_B; ++it) {
-                const int i = tid + it * NTHREADS;
-                pb[it] = (i < C::B_BYTES / 16) ? src[i] : u32x4_t{0u, 0u, 0u, 0u};
-            }
+            for (int it = 0; it < NIT_B; ++it) fetch_b(it);
         }
     };
     auto commit = [&](bool with_a, bool with_b) {
@@ -312,14 +317,67 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
     };
 
     f32x4_t acc[MT][NT];
+    // Deferred epilogue stores: a finished tile's outputs are kept packed in registers and written at the START of
+    // the next stage, BEFORE that stage's prefetch loads are issued.  The wait in front of the LDS commit
+    // (s_waitcnt vmcnt(0) at the loop head) then only sees operations that had a whole MFMA phase to complete,
+    // instead of stalling every tile on the write latency of stores issued just before it.
+    using PendT = typename std::conditional<sizeof(T) == 2, bf16x4_t, f32x4_t>::type;
+    PendT pend[MT][NT];
+    TileCo ptc{0, 0, 0, 0};
+    bool pend_valid = false;
+    auto store_one = [&](int m, int j) {
+        const int v = (wave * MT + m) * 16 + r;
+        const int td = v / (TH * TW), th = (v / TW) % TH, tw = v % TW;
+        const int d = ptc.d0 + td, h = ptc.h0 + th, w = ptc.w0 + tw;
+        if (d >= p.D || h >= p.H || w >= p.W) return;
+        const int co = coutblk * COUTB + j * 16 + q * 4;
+        if (co + 4 > p.M) return;
+        T* dst;
+        if constexpr (EPI == EPI_STORE) {
+            const long long vox = (((long long)ptc.n * p.D + d) * p.H + h) * p.W + w;
+            dst = yg + vox * p.ldy + co;
+        } else {
+            int tt = w;
+            const int dw = tt % p.OW; tt /= p.OW;
+            const int dh = tt % p.OH; tt /= p.OH;
+            const int dd = tt % p.OD, dn = tt / p.OD;
+            const int abc = co / p.creal;
+            const int cbase = co - abc * p.creal;
+            const int fd = 2 * dd + (abc >> 2), fh = 2 * dh + ((abc >> 1) & 1), fw = 2 * dw + (abc & 1);
+            const long long fv = (((long long)dn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
+            dst = yg + fv * p.ldy + cbase;
+        }
+        *(PendT*)dst = pend[m][j];
+    };
+    auto store_pending = [&]() {
+        if (!pend_valid) return;
+        pend_valid = false;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) store_one(m, j);
+    };
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto mark = [&](int k) {
+        if constexpr (DIAG == 5) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            ph[k] += now - tprev;
+            tprev = now;
+        }
+    };
+    if constexpr (DIAG == 5) tprev = __builtin_readcyclecounter();
     int tile = blockIdx.x, kb = 0, ks = 0;
     TileCo tc = decode(tile < p.ntiles ? tile : 0);
     bool a_pending = true, b_pending = true;
     if (tile < p.ntiles) fetch(tc, 0, 0, true, true);
     while (tile < p.ntiles) {
         __syncthreads();  // everyone finished reading the previous stage's LDS image
+        mark(0);
+        if constexpr (DIAG == 5) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(1); }
         commit(a_pending, b_pending);
+        if constexpr (DIAG == 5) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); mark(2); }
         __syncthreads();
+        mark(3);
         // next stage: (tile, kb, ks) advance ks fastest
         int ntile = tile, nkb = kb, nks = ks + 1;
         if (nks == NSL) {
@@ -330,7 +388,27 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
         const TileCo ntc = decode(ntile < p.ntiles ? ntile : 0);
         a_pending = nks == 0;
         b_pending = NSL > 1 || p.NKB > 1;
-        if (ntile < p.ntiles) fetch(ntc, nkb, nks, a_pending, b_pending);
+        // Side work of this stage, issued from slots spread over the MFMA loop so that it overlaps the matrix pipe
+        // instead of serialising all waves in front of it: the previous tile's output stores (held in pend[][]),
+        // then the next stage's halo and weight loads.
+        const bool st_now = pend_valid, ld_now = ntile < p.ntiles;
+        pend_valid = false;
+        fetch_setup(ntc, nkb, nks);
+        constexpr int NI_ST = MT * NT, NI = NI_ST + NIT_A + NIT_B;
+        auto side_item = [&](int i) {
+            if (i < NI_ST) {
+                if (st_now) store_one(i / NT, i % NT);
+            } else if (i < NI_ST + NIT_A) {
+                if (ld_now && a_pending) fetch_a(i - NI_ST);
+            } else {
+                if (ld_now && b_pending) fetch_b(i - NI_ST - NIT_A);
+            }
+        };
+        if constexpr (NSL > 1) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) side_item(i);
+        }
+        mark(4);
 
         const int n = tc.n, d0 = tc.d0, h0 = tc.h0, w0 = tc.w0;
         if (kb == 0 && ks == 0) {
@@ -355,23 +433,86 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
                 const int tap = (NSL > 1) ? t : t;   // local tap within the slice; (kh, kw) from t when sliced by kd
                 const int kd = (NSL > 1) ? 0 : tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
                 const int toff = (NTAPS == 27) ? ((kd * PH + kh) * PW + kw) * 16 : 0;
+                if constexpr (DIAG == 2) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bf[buf][j] = u32x4_t{(unsigned)(t + j), 1u, 2u, 3u};
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) af[buf][m] = u32x4_t{(unsigned)(t + m), 5u, 6u, 7u};
+                    return;
+                }
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     bf[buf][j] = *(const u32x4_t*)(ldsB + bbase + t * (4 * COUTB * 16) + j * 256);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) af[buf][m] = *(const u32x4_t*)(ldsA + abase[m] + ksoff + toff);
             };
-            if constexpr (NSL == 1) {
+            if constexpr (HREUSE) {
+                // Row-reuse order (k3, 16-wide tiles whose MT voxel rows per wave are consecutive in h): for a fixed
+                // (kd, kw) an activation row of the halo feeds up to three output rows (kh = 0..2), so it is read from
+                // LDS once instead of three times and the weights of the three kh taps stay in registers while the
+                // MT+2 halo rows stream past: 108 fragment reads per stage instead of 162 for the same 216 MFMAs.
+                u32x4_t wf[3][NT], xf[2];
+                const int xb = abase[0];
+                auto ldw = [&](int g, int kh) {
+                    const int tap = (g / 3) * 9 + kh * 3 + (g % 3);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        wf[kh][j] = *(const u32x4_t*)(ldsB + bbase + tap * (4 * COUTB * 16) + j * 256);
+                };
+                auto ldx = [&](int g, int hr, int buf) {
+                    xf[buf] = *(const u32x4_t*)(ldsA + xb + (((g / 3) * PH + hr) * PW + (g % 3)) * 16);
+                };
+                constexpr int NSTEP = 9 * (MT + 2);
+                ldw(0, 0); ldw(0, 1); ldw(0, 2);
+                ldx(0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 9; ++g) {
+#pragma unroll
+                    for (int hr = 0; hr < MT + 2; ++hr) {
+                        const int step = g * (MT + 2) + hr, cur = step & 1;
+                        if (hr + 1 < MT + 2) ldx(g, hr + 1, cur ^ 1);
+                        else if (g + 1 < 9) ldx(g + 1, 0, cur ^ 1);
+#pragma unroll
+                        for (int i = 0; i < NI; ++i)
+                            if (i * NSTEP / NI == step) side_item(i);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh) {
+                            const int m = hr - kh;
+                            if (m >= 0 && m < MT) {
+#pragma unroll
+                                for (int j = 0; j < NT; ++j) mma_chunk<T>(acc[m][j], wf[kh][j], xf[cur]);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        // a kh tap's weights are free once its last output row is issued: refill for the next (kd, kw)
+                        if (g + 1 < 9) {
+                            if (hr == MT - 1) ldw(g + 1, 0);
+                            if (hr == MT) ldw(g + 1, 1);
+                            if (hr == MT + 1) ldw(g + 1, 2);
+                        }
+                    }
+                }
+            } else if constexpr (NSL == 1) {
                 load_frags(0, 0);
 #pragma unroll
                 for (int t = 0; t < BT; ++t) {
                     const int cur = t & 1;
                     if (t + 1 < BT) load_frags(t + 1, cur ^ 1);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        if (i * BT / NI == t) side_item(i);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) mma_chunk<T>(acc[m][j], bf[cur][j], af[cur][m]);
+                        for (int j = 0; j < NT; ++j) {
+                            if constexpr (DIAG == 1) {
+                                asm volatile("" ::"v"(bf[cur][j]), "v"(af[cur][m]));   // keep the reads alive, no MFMA
+                            } else {
+                                mma_chunk<T>(acc[m][j], bf[cur][j], af[cur][m]);
+                            }
+                        }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -387,6 +528,12 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
                 }
             }
         }
+        // the held outputs are written by now: give them a definite (dead) state so they free their registers
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) pend[m][j] = PendT{};
+        mark(5);
         if (kb == p.NKB - 1 && ks == NSL - 1) {
             // ---------------- epilogue ----------------
     #pragma unroll
@@ -423,12 +570,20 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
                         const long long fv = (((long long)dn * (2 * p.OD) + fd) * (2 * p.OH) + fh) * (2 * p.OW) + fw;
                         dst = yg + fv * p.ldy + cbase;
                     }
+                    if constexpr (DIAG == 3) {
+                        asm volatile("" ::"v"(o));
+                        continue;
+                    }
                     if (p.vec_store && co + 4 <= p.M) {
                         if (p.bias) {
     #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] += p.bias[cbase + e];
                         }
-                        store4<T>(dst, o);
+                        if constexpr (sizeof(T) == 2) {
+                            pend[m][j] = bf16x4_t{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+                        } else {
+                            pend[m][j] = o;
+                        }
                     } else {
                         for (int e = 0; e < 4 && co + e < p.M; ++e) {
                             o[e] += (p.bias ? p.bias[cbase + e] : 0.f);
@@ -470,7 +625,16 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
                 }
             }
         }
+        if (kb == p.NKB - 1 && ks == NSL - 1 && p.vec_store) { ptc = tc; pend_valid = true; }
+        mark(6);
         tile = ntile; kb = nkb; ks = nks; tc = ntc;
+    }
+    store_pending();
+    if constexpr (DIAG == 5) {
+        if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g_phase_cycles[k] = ph[k];
+        }
     }
     if constexpr (EPI == EPI_STORE) {
         if (do_stats) {
@@ -531,7 +695,7 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
     }
 }
 
-template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1, int NSL = 1>
+template <typename T, int NTAPS, int SRC, int EPI, int TD, int TH, int TW, int WAVES, int NT, int STRIDE = 1, int NSL = 1, int DIAG = 0>
 int launch_cfg(IgemmParams& p, hipStream_t stream) {
     using C = IgemmCfg<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE, NSL>;
     p.tiles_d = ceil_div(p.D, TD);
@@ -546,7 +710,7 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
         const long long xh = STRIDE == 1 ? p.H : p.IH, xw = STRIDE == 1 ? p.W : p.IW;
         p.rel32_ok = ((long long)(C::PD + 1) * xh * xw * p.ldx < 0x7fffffffLL) ? 1 : 0;
     }
-    auto kern = igemm_fwd_kernel<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE, NSL>;
+    auto kern = igemm_fwd_kernel<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE, NSL, DIAG>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) !=
@@ -600,6 +764,19 @@ template <typename T> int launch_k3(IgemmParams& p, hipStream_t stream) {
         // A/B switch.  Measured on MI355X (round 1): the tap-sliced 2-WG/CU variant is SLOWER (32->32 @96^3: 144 us
         // vs 110 us) -- weight-slice refetch + 3x barriers cost more than the second workgroup hides.
         static const bool old_big = getenv("MSSEG_K3_SLICED") == nullptr;
+        if constexpr (sizeof(T) == 2) {
+            static const char* diag = getenv("MSSEG_DIAG");   // timing-only ablations of the dominant kernel
+            if (diag && cb == 32) {
+                p.cout_block = 32;
+                switch (diag[0]) {
+                    case '1': return launch_cfg<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8, 2, 1, 1, 1>(p, stream);
+                    case '2': return launch_cfg<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8, 2, 1, 1, 2>(p, stream);
+                    case '3': return launch_cfg<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8, 2, 1, 1, 3>(p, stream);
+                    case '4': return launch_cfg<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8, 2, 1, 1, 4>(p, stream);
+                    case '5': return launch_cfg<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8, 2, 1, 1, 5>(p, stream);
+                }
+            }
+        }
         if (old_big || cb == 48) return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 4, 8, 16, 8>(p, stream);  // 48-wide: sliced variant spills
         return launch_nt<T, 27, SRC_DIRECT, EPI_STORE, 2, 8, 16, 4, 1, 3>(p, stream);
     }
@@ -621,6 +798,11 @@ int check_common(const void* x, long long ldx, const void* wp, const void* y, lo
 }
 
 }  // namespace
+
+// tools-only (not part of include/msseg.h): cycle counters written by the MSSEG_DIAG=5 build of the big-tile kernel
+extern "C" int msseg_debug_phase_cycles(unsigned long long* out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 
 extern "C" {
 
@@ -695,6 +877,19 @@ static int k3_fwd_impl(const void* x, long long ldx, const void* wp, const float
         p.nb_y = nb_y; p.nb_ldy = nb_ldy; p.nb_a = nb_a; p.nb_lda = nb_lda; p.nb_stats = nb_stats;
         p.nb_slope = nb_slope; p.nb_eps = nb_eps; p.nb_S = (long long)D * H * W;
         p.nb_dgamma = nb_dgamma; p.nb_dbeta = nb_dbeta; p.nb_acc = nb_acc;
+    }
+    if (dtype == MSSEG_BF16) {
+        // the 32-input-channel layers (the 96^3 / 48^3 levels) run on the ping-pong kernel when the grid is large enough
+        K3ppParams pp{};
+        pp.x = x; pp.ldx = ldx; pp.wp = wp; pp.bias = bias; pp.y = y; pp.ldy = ldy;
+        pp.N = N; pp.D = D; pp.H = H; pp.W = W; pp.K = Cin; pp.M = Cout;
+        pp.stats = p.stats; pp.stats_ws = p.stats_ws; pp.counter = p.counter;
+        pp.nb_y = p.nb_y; pp.nb_ldy = p.nb_ldy; pp.nb_a = p.nb_a; pp.nb_lda = p.nb_lda; pp.nb_stats = p.nb_stats;
+        pp.nb_slope = p.nb_slope; pp.nb_eps = p.nb_eps; pp.nb_S = p.nb_S;
+        pp.nb_dgamma = p.nb_dgamma; pp.nb_dbeta = p.nb_dbeta; pp.nb_acc = p.nb_acc;
+        int cfg, cb;
+        k3_plan(N, D, H, W, Cout, &cfg, &cb);   // the packed weight image must be the 32-wide one
+        if (cb == 32 && msseg_k3pp_eligible(pp)) return msseg_k3pp_launch(pp, (hipStream_t)stream);
     }
     return dtype == MSSEG_F32 ? launch_k3<float>(p, (hipStream_t)stream) : launch_k3<bf16_t>(p, (hipStream_t)stream);
 }

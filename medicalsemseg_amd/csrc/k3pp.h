@@ -1,0 +1,26 @@
+// Ping-pong conv3d k3 kernel (bf16, 32 input channels per stage, 32-wide cout blocks): host-side interface.
+#pragma once
+#include "common.h"
+
+struct K3ppParams {
+    const void* x;
+    long long ldx;
+    const void* wp;      // msseg_pack_weights image for cout block 32: [coutblk][kblk][27][4][32][16 B]
+    const float* bias;   // optional
+    void* y;
+    long long ldy;
+    int N, D, H, W, K, M;
+    // optional fused reductions (same meaning as IgemmParams in igemm_fwd.hip)
+    float* stats;
+    float* stats_ws;
+    unsigned int* counter;
+    const void* nb_y; long long nb_ldy;
+    const void* nb_a; long long nb_lda;
+    const float* nb_stats;
+    float nb_slope, nb_eps; long long nb_S;
+    float* nb_dgamma; float* nb_dbeta; int nb_acc;
+};
+
+// true when the problem can run on the ping-pong kernel (otherwise the generic igemm kernel is used)
+bool msseg_k3pp_eligible(const K3ppParams& p);
+int msseg_k3pp_launch(const K3ppParams& p, hipStream_t stream);

@@ -50,7 +50,9 @@ def gen(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,sp", [(32, 32, (16, 16, 16)), (64, 32, (32, 32, 32)), (32, 64, (12, 12, 12)),
                                          (48, 48, (12, 12, 24)), (16, 16, (8, 8, 8)), (128, 256, (6, 6, 6)),
-                                         (96, 48, (6, 10, 18)), (8, 24, (5, 7, 9))])
+                                         (96, 48, (6, 10, 18)), (8, 24, (5, 7, 9)),
+                                         # grids large enough for the ping-pong kernel (bf16, 32 channels per stage)
+                                         (32, 32, (32, 48, 64)), (32, 64, (30, 29, 70)), (64, 32, (34, 31, 50))])
 def test_conv3d_k3_fwd_dgrad_wgrad(dtype, cin, cout, sp):
     from medicalsemseg_amd import hip
     from medicalsemseg_amd.layers import Conv3
@@ -342,7 +344,8 @@ def test_unet_small_fwd_bwd(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cin,cout,sp,N", [(32, 32, (32, 32, 32), 2), (32, 64, (12, 12, 12), 3), (16, 48, (6, 6, 6), 1)])
+@pytest.mark.parametrize("cin,cout,sp,N", [(32, 32, (32, 32, 32), 2), (32, 64, (12, 12, 12), 3), (16, 48, (6, 6, 6), 1),
+                                           (32, 32, (32, 48, 64), 2), (32, 64, (30, 29, 38), 3)])
 def test_conv3d_k3_fused_stats(dtype, cin, cout, sp, N):
     """InstanceNorm statistics from the conv epilogue == statistics of the stored output (separate pass + torch)"""
     from medicalsemseg_amd import hip
@@ -397,7 +400,8 @@ def test_flat_adamw_matches_torch_adamw():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cin,cout,sp,N", [(32, 32, (32, 32, 32), 2), (64, 32, (12, 12, 12), 2), (16, 48, (6, 6, 6), 1)])
+@pytest.mark.parametrize("cin,cout,sp,N", [(32, 32, (32, 32, 32), 2), (64, 32, (12, 12, 12), 2), (16, 48, (6, 6, 6), 1),
+                                           (32, 32, (32, 48, 64), 2), (64, 32, (30, 29, 38), 3)])
 def test_conv_dgrad_fused_instnorm_backward_reductions(dtype, cin, cout, sp, N):
     """da = dgrad(dy) with the InstanceNorm-backward reductions of the receiving layer fused in the epilogue ==
     separate dgrad + msseg_instnorm_act_bwd_reduce"""

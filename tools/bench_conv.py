@@ -51,3 +51,22 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 nbytes = x.numel() * 2 + y.numel() * 2
 print(f"{what} cin={cin} cout={cout} size={size}: {ms*1e3:.1f} us/launch  {flops/ms/1e9:.1f} TFLOP/s  ({nbytes/ms/1e6:.0f} GB/s in+out)")
+if os.environ.get("MSSEG_DIAG") == "5":
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    lib = hip.load_library()
+    lib.msseg_debug_phase_cycles.argtypes = [ctypes.c_void_p]
+    if lib.msseg_debug_phase_cycles(buf) == 0:
+        names = ["barrier0(wait readers)", "vmcnt(0) wait", "commit ds_write", "barrier1", "stores+fetch issue", "MFMA phase", "epilogue", "-"]
+        tot = sum(buf[:7])
+        for n_, v in zip(names, buf):
+            print(f"  {n_:26s} {v:10d} ticks  {100.0 * v / max(tot, 1):5.1f} %")
+        print(f"  total {tot} ticks over the launch of workgroup 0 / wave 0 ({ms*1e3:.1f} us)")
+if os.environ.get("MSSEG_K3PP_TIMING"):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    lib = hip.load_library()
+    lib.msseg_debug_k3pp_cycles.argtypes = [ctypes.c_void_p]
+    if lib.msseg_debug_k3pp_cycles(buf) == 0:
+        names = ["MFMA role", "epilogue", "final vmcnt wait", "barrier wait", "halo load issue", "halo load wait"]
+        print("  wave 0 ticks: " + "  ".join(f"{n_} {v}" for n_, v in zip(names, buf)) + f"  total {sum(buf[:6])}")
