@@ -10,6 +10,7 @@
 // ONE fp32 slab; a second kernel sums the slabs in a fixed order (deterministic) straight into the
 // torch-layout gradient.
 #include "common.h"
+#include "k3pp.h"
 
 #include <stdlib.h>
 
@@ -417,6 +418,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const ReducePar
     }
 }
 
+int launch_reduce(const ReduceParams& rp, hipStream_t stream) {
+    const long long total = (long long)rp.M * rp.T * rp.K;
+    if (rp.nslots <= 32) {
+        int rb = (int)((total + 255) / 256);
+        if (rb > 8192) rb = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3(rb), dim3(256), 0, stream, rp);
+    } else {
+        int rb = (int)((total + 31) / 32);
+        if (rb > 4096) rb = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, rp);
+    }
+    MSSEG_CHECK_LAUNCH("wgrad_reduce");
+    return MSSEG_OK;
+}
+
 template <typename T, int NTAPS, int QSRC, int TD, int TH, int TW>
 int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes, hipStream_t stream) {
     using C = WgCfg<T, NTAPS, TD, TH, TW>;
@@ -455,21 +471,30 @@ int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes
     MSSEG_CHECK_LAUNCH("igemm_wgrad");
     rp.slabs = p.slabs;
     rp.mblks = p.mblks; rp.kblks = p.kblks; rp.nslots = (int)gx * wave_slots; rp.cbw = C::CBW;
-    const long long total = (long long)rp.M * rp.T * rp.K;
-    if (rp.nslots <= 32) {
-        int rb = (int)((total + 255) / 256);
-        if (rb > 8192) rb = 8192;
-        hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3(rb), dim3(256), 0, stream, rp);
-    } else {
-        int rb = (int)((total + 31) / 32);
-        if (rb > 4096) rb = 4096;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, rp);
-    }
-    MSSEG_CHECK_LAUNCH("wgrad_reduce");
-    return MSSEG_OK;
+    return launch_reduce(rp, stream);
 }
 
 template <typename T> int launch_wg_k3(WgradParams& p, ReduceParams& rp, void* ws, size_t wsb, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        // large grids with 32-multiple channel counts: the ping-pong kernel (conv3d_k3_wgrad_pp.hip)
+        K3WgParams pp{};
+        pp.pten = p.pten; pp.ldp = p.ldp; pp.qten = p.qten; pp.ldq = p.ldq;
+        pp.N = p.N; pp.D = p.D; pp.H = p.H; pp.W = p.W; pp.M = p.M; pp.K = p.K; pp.kblks = p.K / 32;
+        if (msseg_k3wg_pp_eligible(pp)) {
+            const int pairs = (p.M / 32) * (p.K / 32);
+            int gx = msseg_k3wg_pp_grid(pp);
+            const long long fit = (long long)(wsb / ((size_t)27 * 32 * 32 * 4 * pairs));
+            if (fit >= 8) {
+                if (gx > fit) gx = (int)(fit & ~7LL);
+                pp.slabs = (float*)ws;
+                const int rc = msseg_k3wg_pp_launch(pp, gx, st);
+                if (rc) return rc;
+                rp.slabs = pp.slabs;
+                rp.mblks = p.M / 32; rp.kblks = p.K / 32; rp.nslots = gx; rp.cbw = 32;
+                return launch_reduce(rp, st);
+            }
+        }
+    }
     const int mn = p.D < p.H ? (p.D < p.W ? p.D : p.W) : (p.H < p.W ? p.H : p.W);
     if (mn >= 32) {
         static const bool two_wg = getenv("MSSEG_WGRAD_2WG") != nullptr;   // A/B switch

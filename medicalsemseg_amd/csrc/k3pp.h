@@ -24,3 +24,15 @@ struct K3ppParams {
 // true when the problem can run on the ping-pong kernel (otherwise the generic igemm kernel is used)
 bool msseg_k3pp_eligible(const K3ppParams& p);
 int msseg_k3pp_launch(const K3ppParams& p, hipStream_t stream);
+
+// ---- weight gradient (conv3d_k3_wgrad_pp.hip) ----
+struct K3WgParams {
+    const void* pten; long long ldp;   // dy (channels M)
+    const void* qten; long long ldq;   // x  (channels K)
+    float* slabs;                      // [pair = mblk * kblks + kblk][workgroup][27][32][32] fp32 partial sums
+    int N, D, H, W, M, K, kblks;
+    int dbg_noload;                    // timing experiments only
+};
+bool msseg_k3wg_pp_eligible(const K3WgParams& p);
+int msseg_k3wg_pp_grid(const K3WgParams& p);      // workgroups per block pair (= slabs per pair)
+int msseg_k3wg_pp_launch(const K3WgParams& p, int gx, hipStream_t stream);

@@ -70,3 +70,8 @@ if os.environ.get("MSSEG_K3PP_TIMING"):
     if lib.msseg_debug_k3pp_cycles(buf) == 0:
         names = ["MFMA role", "epilogue", "final vmcnt wait", "barrier wait", "halo load issue", "halo load wait"]
         print("  wave 0 ticks: " + "  ".join(f"{n_} {v}" for n_, v in zip(names, buf)) + f"  total {sum(buf[:6])}")
+if os.environ.get("MSSEG_K3PP_TIMING") and what == "wgrad":
+    buf4 = (ctypes.c_ulonglong * 4)()
+    lib.msseg_debug_k3wg_cycles.argtypes = [ctypes.c_void_p]
+    if lib.msseg_debug_k3wg_cycles(buf4) == 0:
+        print("  wgrad wave 0 ticks: MFMA role %d  memory role %d  vmcnt wait %d  barrier wait %d" % tuple(buf4))
