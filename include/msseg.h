@@ -53,6 +53,18 @@ size_t msseg_packed_weight_bytes(int M, int T, int K, int cout_block, int dtype)
 int msseg_pack_weights(const float* src, void* dst, int dtype, int M, int M0, int T, int K, int K0,
                        long long s_m1, long long s_m0, long long s_t, long long s_k1, long long s_k0,
                        int flip, int cout_block, msseg_stream_t stream);
+/* Batched form: one launch repacks every job of a device-resident table (all jobs share `dtype`).  Used once per
+ * optimizer step to refresh all packed images of a network (reference equivalent: none -- torch.nn.Conv3d reads the
+ * fp32 parameter directly, /root/reference/run_training.py:92-93 updates it in place). */
+typedef struct msseg_pack_job {
+    const float* src;
+    void* dst;
+    long long s_m1, s_m0, s_t, s_k1, s_k0;
+    long long total;          /* elements of the destination image = msseg_packed_weight_bytes / element size */
+    int M, M0, T, K, K0, flip, cout_block, nkb;   /* nkb = ceil(K / (64 / element size)) */
+} msseg_pack_job;
+int msseg_pack_weights_batch(const msseg_pack_job* jobs_dev, int njobs, long long max_total, int dtype,
+                             msseg_stream_t stream);
 /* cout block (16/32/48) the igemm kernels use for a layer with M logical output channels */
 int msseg_cout_block(int M);
 /* cout block msseg_conv3d_k3_fwd will use for this problem (pack the weights with it) */

@@ -693,6 +693,31 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const msseg_pack_job* __restrict__ jobs) {
+    constexpr int EPC = DT<T>::EPC;
+    const msseg_pack_job j = jobs[blockIdx.y];
+    T* dst = (T*)j.dst;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < j.total; i += (long long)gridDim.x * 256) {
+        long long t = i;
+        const int e = (int)(t % EPC); t /= EPC;
+        const int col = (int)(t % j.cout_block); t /= j.cout_block;
+        const int q = (int)(t % 4); t /= 4;
+        const int tap = (int)(t % j.T); t /= j.T;
+        const int kb = (int)(t % j.nkb);
+        const int cb = (int)(t / j.nkb);
+        const int m = cb * j.cout_block + col;
+        const int k = kb * 4 * EPC + q * EPC + e;
+        float v = 0.f;
+        if (m < j.M && k < j.K) {
+            const int tt = j.flip ? (j.T - 1 - tap) : tap;
+            v = j.src[(long long)(m / j.M0) * j.s_m1 + (long long)(m % j.M0) * j.s_m0 + (long long)tt * j.s_t +
+                      (long long)(k / j.K0) * j.s_k1 + (long long)(k % j.K0) * j.s_k0];
+        }
+        DT<T>::st(dst + i, v);
+    }
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, const uint8_t* __restrict__ decay, long long n, float lr, float b1,
                              float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* gscale,
@@ -765,6 +790,18 @@ int msseg_pack_weights(const float* src, void* dst, int dtype, int M, int M0, in
                hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                                   src, (bf16_t*)dst, M, M0, T, K, K0, s_m1, s_m0, s_t, s_k1, s_k0, flip, cout_block, nkb, total));
     MSSEG_CHECK_LAUNCH("pack_weights");
+    return MSSEG_OK;
+}
+
+int msseg_pack_weights_batch(const msseg_pack_job* jobs_dev, int njobs, long long max_total, int dtype,
+                             msseg_stream_t stream) {
+    if (!jobs_dev || njobs < 1 || njobs > 65535 || max_total < 1) MSSEG_FAIL(MSSEG_EINVAL, "pack_weights_batch: bad args");
+    long long gx = ceil_div_ll(max_total, 256LL * 8);
+    if (gx > 64) gx = 64;
+    dim3 grid((unsigned)gx, (unsigned)njobs);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev),
+               hipLaunchKernelGGL(pack_weights_batch_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev));
+    MSSEG_CHECK_LAUNCH("pack_weights_batch");
     return MSSEG_OK;
 }
 

@@ -29,6 +29,7 @@ SIGNATURES = {
     "msseg_num_cus": ([], _i),
     "msseg_packed_weight_bytes": ([_i, _i, _i, _i, _i], _sz),
     "msseg_pack_weights": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp], _i),
+    "msseg_pack_weights_batch": ([_vp, _i, _ll, _i, _vp], _i),
     "msseg_cout_block": ([_i], _i),
     "msseg_conv3d_k3_cout_block": ([_i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_variant": ([_i, _i, _i, _i, _i], _i),
@@ -167,8 +168,23 @@ def conv_k3_cout_block(N, D, H, W, cout) -> int:
     return lib().msseg_conv3d_k3_cout_block(N, D, H, W, cout)
 
 
+class PackJob(C.Structure):
+    """mirror of msseg_pack_job (include/msseg.h)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p),
+                ("s_m1", C.c_longlong), ("s_m0", C.c_longlong), ("s_t", C.c_longlong), ("s_k1", C.c_longlong),
+                ("s_k0", C.c_longlong), ("total", C.c_longlong),
+                ("M", C.c_int), ("M0", C.c_int), ("T", C.c_int), ("K", C.c_int), ("K0", C.c_int), ("flip", C.c_int),
+                ("cout_block", C.c_int), ("nkb", C.c_int)]
+
+
+# the most recent pack_weights call as a (src, dst, PackJob) triple: layers.PackedCache registers it for the
+# once-per-step batched refresh
+LAST_PACK_JOB = None
+
+
 def pack_weights(src: torch.Tensor, dtype: torch.dtype, M, M0, T, K, K0, s_m1, s_m0, s_t, s_k1, s_k0, flip=False,
                  out: Optional[torch.Tensor] = None, cb: Optional[int] = None) -> torch.Tensor:
+    global LAST_PACK_JOB
     _need_gpu(src)
     assert src.dtype == torch.float32 and src.is_contiguous()
     cb = cb or cout_block(M)
@@ -179,7 +195,14 @@ def pack_weights(src: torch.Tensor, dtype: torch.dtype, M, M0, T, K, K0, s_m1, s
     assert out.numel() * esz == nbytes
     _ck(lib().msseg_pack_weights(_p(src), _p(out), _DT[dtype], M, M0, T, K, K0, s_m1, s_m0, s_t, s_k1, s_k0,
                                  int(flip), cb, _stream()), "pack_weights")
+    LAST_PACK_JOB = (src, out, PackJob(_p(src), _p(out), s_m1, s_m0, s_t, s_k1, s_k0, nbytes // esz, M, M0, T, K, K0,
+                                       int(flip), cb, -(-K // (64 // esz))))
     return out
+
+
+def pack_weights_batch(table: torch.Tensor, njobs: int, max_total: int, dtype: torch.dtype):
+    """table: uint8 device tensor holding njobs consecutive PackJob structs"""
+    _ck(lib().msseg_pack_weights_batch(_p(table), njobs, max_total, _DT[dtype], _stream()), "pack_weights_batch")
 
 
 def pack_conv_k3(w: torch.Tensor, dtype, dgrad=False, out=None, vol=None):

@@ -26,22 +26,77 @@ def bump_weights_epoch():
     weights_epoch += 1
 
 
+class _PackRegistry:
+    """Every packed-weight image built through a PackedCache, grouped by (device, compute dtype).  When any image is
+    found stale (its parameter changed: optimizer step, load_state_dict, in-place edit) ALL images of the group are
+    rebuilt by ONE msseg_pack_weights_batch launch instead of one launch per image."""
+
+    def __init__(self):
+        self.groups = {}
+
+    def add(self, device, dtype, src, dst, job):
+        g = self.groups.setdefault((device, dtype), {"jobs": [], "table": None, "keep": []})
+        rec = {"src": src, "dst": dst, "job": job, "state": (src._version, weights_epoch), "alive": True}
+        g["jobs"].append(rec)
+        g["table"] = None
+        return rec
+
+    def drop(self, device, dtype, rec):
+        g = self.groups.get((device, dtype))
+        if g is not None and rec["alive"]:
+            rec["alive"] = False
+            g["jobs"] = [r for r in g["jobs"] if r["alive"]]
+            g["table"] = None
+
+    def refresh(self, device, dtype):
+        import ctypes
+        g = self.groups[(device, dtype)]
+        jobs = g["jobs"]
+        if g["table"] is None:
+            arr = (hip.PackJob * len(jobs))(*[r["job"] for r in jobs])
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            if g.get("last") is not None:
+                g["keep"].append(g["last"])   # a captured hipGraph may still reference the previous table
+            g["table"] = g["last"] = host.to(device)
+            g["max_total"] = max(int(r["job"].total) for r in jobs)
+        hip.pack_weights_batch(g["table"], len(jobs), g["max_total"], dtype)
+        for r in jobs:
+            r["state"] = (r["src"]._version, weights_epoch)
+
+
+PACK_REGISTRY = _PackRegistry()
+
+
 class PackedCache:
     """Packed-weight images of one parameter, rebuilt when the parameter changed."""
 
     def __init__(self):
-        self._key = None
         self._val = {}
 
+    def __del__(self):
+        try:
+            for (dtype, _), rec in self._val.items():
+                PACK_REGISTRY.drop(rec["src"].device, dtype, rec)
+        except Exception:   # interpreter shutdown
+            pass
+
     def get(self, p: torch.Tensor, dtype, kind: str, builder):
-        key = (p.data_ptr(), p._version, weights_epoch, dtype, p.device)
-        if key != self._key:
-            self._key, self._val = key, {}
-        v = self._val.get(kind)
-        if v is None:
+        k = (dtype, kind)
+        rec = self._val.get(k)
+        if rec is not None and (rec["src"].data_ptr() != p.data_ptr() or rec["src"].device != p.device):
+            PACK_REGISTRY.drop(rec["src"].device, dtype, rec)   # the parameter moved: rebuild from scratch
+            rec = None
+        if rec is None:
+            hip.LAST_PACK_JOB = None
             v = builder()
-            self._val[kind] = v
-        return v
+            src, dst, job = hip.LAST_PACK_JOB
+            assert dst.data_ptr() == v.data_ptr()
+            rec = PACK_REGISTRY.add(p.device, dtype, src, dst, job)
+            self._val[k] = rec
+            return v
+        if rec["state"] != (rec["src"]._version, weights_epoch):
+            PACK_REGISTRY.refresh(p.device, dtype)
+        return rec["dst"]
 
 
 def _grad_buf(p: torch.nn.Parameter):
