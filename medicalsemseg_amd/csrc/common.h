@@ -96,6 +96,31 @@ MSSEG_DEVFN bool grid_last_block(unsigned int* counter, unsigned int total_block
     return *lds_flag != 0;
 }
 
+// Fixed-order sum of R partial rows of L floats (L % 4 == 0, L <= 4 * NT) by one block of NT threads: float4-wide,
+// every thread with up to 8 independent loads in flight, row slots then combined through LDS in a fixed order
+// (bit-reproducible).  The L totals end up in lds[NT * 4 ..]; lds: >= NT * 4 + L floats, 16-byte aligned.
+template <int NT>
+MSSEG_DEVFN void block_rows_sum(const float* rows, int R, int L, float* lds) {
+    const int tid = threadIdx.x, q = L >> 2;
+    const int SL = NT / q;
+    const int c4 = tid % q, slot = tid / q;
+    f32x4_t* l4 = (f32x4_t*)lds;
+    if (slot < SL) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        const f32x4_t* src = (const f32x4_t*)rows + c4;
+#pragma unroll 8
+        for (int x = slot; x < R; x += SL) acc += src[(long long)x * q];
+        l4[slot * q + c4] = acc;
+    }
+    __syncthreads();
+    if (tid < q) {
+        f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < SL; ++sl) t += l4[sl * q + tid];
+        l4[NT + tid] = t;
+    }
+    __syncthreads();
+}
+
 #define MSSEG_SCRATCH_COUNTER_BYTES 256
 #define MSSEG_STATS_NMAX 8
 

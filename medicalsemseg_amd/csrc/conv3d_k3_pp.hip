@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
         }
     }
 
-    // ---- fused reductions: waves -> workgroup -> grid ("last block finalises", fixed order throughout) ------------
+    // ---- fused reductions: waves -> workgroup partial row; rows are added by msseg_k3_stats_finalize (fixed order) ----
     if constexpr (STATS != 0) {
         flush_stats();
         __syncthreads();
@@ -329,56 +329,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
 #pragma unroll
             for (int wv = 0; wv < 8; ++wv) s += ldsS[wv * MSSEG_STATS_NMAX * 64 + i];
             wsp[i] = s;
-        }
-        int* flag = (int*)ldsH;   // halo images are dead by now
-        if (grid_last_block(p.counter, gridDim.x * gridDim.y, flag)) {
-            constexpr int PARTS = 16;
-            const int nch = gridDim.y * 32;
-            const int sub = tid % PARTS;
-            for (int base = 0; base < nch; base += NTHREADS / PARTS) {
-                const int o = base + tid / PARTS;
-                const bool ok = o < nch;
-                const int yb = ok ? o / 32 : 0, cl = ok ? o % 32 : 0;
-                const int cg = yb * 32 + cl;
-                float g0 = 0.f, g1 = 0.f;
-                for (int nn = 0; nn < p.N; ++nn) {
-                    float a = 0.f, b = 0.f;
-                    if (ok) {
-                        const float* src = p.stats_ws + (long long)yb * gridDim.x * PN + (nn * 32 + cl) * 2;
-#pragma unroll 8
-                        for (int x = sub; x < (int)gridDim.x; x += PARTS) {
-                            a += src[(long long)x * PN];
-                            b += src[(long long)x * PN + 1];
-                        }
-                    }
-#pragma unroll
-                    for (int o2 = 1; o2 < PARTS; o2 <<= 1) {
-                        a += __shfl_xor(a, o2);
-                        b += __shfl_xor(b, o2);
-                    }
-                    if (ok && sub == 0 && cg < p.M) {
-                        if constexpr (STATS == 2) {
-                            const float inv = 1.0f / (float)p.nb_S;
-                            const float fs = p.nb_stats[((long long)nn * p.M + cg) * 2];
-                            const float fs2 = p.nb_stats[((long long)nn * p.M + cg) * 2 + 1];
-                            const float mean = fs * inv;
-                            float var = fs2 * inv - mean * mean;
-                            var = var > 0.f ? var : 0.f;
-                            b = rsqrtf(var + p.nb_eps) * (b - mean * a);
-                            g0 += a;
-                            g1 += b;
-                        }
-                        p.stats[((long long)nn * p.M + cg) * 2 + 0] = a;
-                        p.stats[((long long)nn * p.M + cg) * 2 + 1] = b;
-                    }
-                }
-                if constexpr (STATS == 2) {
-                    if (ok && sub == 0 && cg < p.M && p.nb_dgamma != nullptr) {
-                        p.nb_dbeta[cg] = p.nb_acc ? p.nb_dbeta[cg] + g0 : g0;
-                        p.nb_dgamma[cg] = p.nb_acc ? p.nb_dgamma[cg] + g1 : g1;
-                    }
-                }
-            }
         }
     }
 }
@@ -400,6 +350,13 @@ template <int STATS, int TIMING> int launch(const K3ppParams& p, hipStream_t str
     if (gx > tiles) gx = tiles;
     hipLaunchKernelGGL(kern, dim3(gx, ncb, 1), dim3(NTHREADS), lds, stream, p);
     MSSEG_CHECK_LAUNCH("conv3d_k3_pp");
+    if (STATS != 0) {
+        K3FinParams f{};
+        f.ws = p.stats_ws; f.R = gx; f.N = p.N; f.coutb = 32; f.M = p.M; f.stats = p.stats;
+        f.nb_stats = (STATS == 2) ? p.nb_stats : nullptr; f.nb_eps = p.nb_eps; f.nb_S = p.nb_S;
+        f.nb_dgamma = p.nb_dgamma; f.nb_dbeta = p.nb_dbeta; f.nb_acc = p.nb_acc;
+        return msseg_k3_stats_finalize(f, ncb, stream);
+    }
     return MSSEG_OK;
 }
 

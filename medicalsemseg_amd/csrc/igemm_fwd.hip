@@ -643,54 +643,43 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
             const int PN = p.N * COUTB * 2;
             float* wsp = p.stats_ws + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * PN;
             for (int i = tid; i < PN; i += NTHREADS) wsp[i] = spart[i];
-            int* flag = (int*)(wpart + WAVES * COUTB * 2);
-            if (grid_last_block(p.counter, gridDim.x * gridDim.y, flag)) {
-                // 16 lanes share one (cout) output pair, every lane keeps up to 16 loads in flight; fixed order
-                constexpr int PARTS = 16;
-                const int nch = gridDim.y * COUTB;
-                const int sub = tid % PARTS;
-                for (int base = 0; base < nch; base += NTHREADS / PARTS) {
-                    const int o = base + tid / PARTS;
-                    const bool ok = o < nch;
-                    const int y = ok ? o / COUTB : 0, cl = ok ? o % COUTB : 0;
-                    const int cg = y * COUTB + cl;
-                    float g0 = 0.f, g1 = 0.f;
-                    for (int nn = 0; nn < p.N; ++nn) {
-                        float s0 = 0.f, s1 = 0.f;
-                        if (ok) {
-                            const float* src = p.stats_ws + (long long)y * gridDim.x * PN + (nn * COUTB + cl) * 2;
-#pragma unroll 8
-                            for (int x = sub; x < (int)gridDim.x; x += PARTS) {
-                                s0 += src[(long long)x * PN];
-                                s1 += src[(long long)x * PN + 1];
-                            }
-                        }
-#pragma unroll
-                        for (int o2 = 1; o2 < PARTS; o2 <<= 1) {
-                            s0 += __shfl_xor(s0, o2);
-                            s1 += __shfl_xor(s1, o2);
-                        }
-                        if (ok && sub == 0 && cg < p.M) {
-                            if (p.nb_y != nullptr) {
-                                const float inv = 1.0f / (float)p.nb_S;
-                                const float fs = p.nb_stats[((long long)nn * p.M + cg) * 2], fs2 = p.nb_stats[((long long)nn * p.M + cg) * 2 + 1];
-                                const float mean = fs * inv;
-                                float var = fs2 * inv - mean * mean;
-                                var = var > 0.f ? var : 0.f;
-                                s1 = rsqrtf(var + p.nb_eps) * (s1 - mean * s0);
-                                g0 += s0;
-                                g1 += s1;
-                            }
-                            p.stats[((long long)nn * p.M + cg) * 2 + 0] = s0;
-                            p.stats[((long long)nn * p.M + cg) * 2 + 1] = s1;
-                        }
-                    }
-                    if (ok && sub == 0 && cg < p.M && p.nb_y != nullptr && p.nb_dgamma != nullptr) {
-                        p.nb_dbeta[cg] = p.nb_acc ? p.nb_dbeta[cg] + g0 : g0;
-                        p.nb_dgamma[cg] = p.nb_acc ? p.nb_dgamma[cg] + g1 : g1;
-                    }
-                }
-            }
+        }
+    }
+}
+
+// second step of the fused epilogue reductions: see K3FinParams (k3pp.h)
+__global__ __launch_bounds__(256) void k3_stats_finalize_kernel(const K3FinParams f) {
+    __shared__ __attribute__((aligned(16))) float fin[256 * 4 + 8 * 48 * 2];
+    const int tid = threadIdx.x;
+    const int L = f.N * f.coutb * 2;
+    block_rows_sum<256>(f.ws + (long long)blockIdx.x * f.R * L, f.R, L, fin);
+    const float* tot = fin + 256 * 4;   // [n][cl][2]
+    const int cbase = blockIdx.x * f.coutb;
+    if (f.nb_stats == nullptr) {
+        for (int i = tid; i < L; i += 256) {
+            const int n = i / (f.coutb * 2), cl = (i % (f.coutb * 2)) >> 1, k = i & 1;
+            if (cbase + cl < f.M) f.stats[((long long)n * f.M + cbase + cl) * 2 + k] = tot[i];
+        }
+    } else if (tid < f.coutb && cbase + tid < f.M) {
+        // sum dz*xhat = rstd * (sum dz*yraw - mean * sum dz); dbeta / dgamma = sums over the samples
+        const int cg = cbase + tid;
+        float g0 = 0.f, g1 = 0.f;
+        const float inv = 1.0f / (float)f.nb_S;
+        for (int nn = 0; nn < f.N; ++nn) {
+            const float a = tot[(nn * f.coutb + tid) * 2], b0 = tot[(nn * f.coutb + tid) * 2 + 1];
+            const float fs = f.nb_stats[((long long)nn * f.M + cg) * 2], fs2 = f.nb_stats[((long long)nn * f.M + cg) * 2 + 1];
+            const float mean = fs * inv;
+            float var = fs2 * inv - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            const float b2 = rsqrtf(var + f.nb_eps) * (b0 - mean * a);
+            g0 += a;
+            g1 += b2;
+            f.stats[((long long)nn * f.M + cg) * 2 + 0] = a;
+            f.stats[((long long)nn * f.M + cg) * 2 + 1] = b2;
+        }
+        if (f.nb_dgamma != nullptr) {
+            f.nb_dbeta[cg] = f.nb_acc ? f.nb_dbeta[cg] + g0 : g0;
+            f.nb_dgamma[cg] = f.nb_acc ? f.nb_dgamma[cg] + g1 : g1;
         }
     }
 }
@@ -726,6 +715,13 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
     dim3 grid(gx, ncb, 1);
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
     MSSEG_CHECK_LAUNCH("igemm_fwd");
+    if (EPI == EPI_STORE && p.stats != nullptr) {
+        K3FinParams f{};
+        f.ws = p.stats_ws; f.R = gx; f.N = p.N; f.coutb = C::COUTB; f.M = p.M; f.stats = p.stats;
+        f.nb_stats = p.nb_y ? p.nb_stats : nullptr; f.nb_eps = p.nb_eps; f.nb_S = p.nb_S;
+        f.nb_dgamma = p.nb_dgamma; f.nb_dbeta = p.nb_dbeta; f.nb_acc = p.nb_acc;
+        return msseg_k3_stats_finalize(f, ncb, stream);
+    }
     return MSSEG_OK;
 }
 
@@ -799,6 +795,12 @@ int check_common(const void* x, long long ldx, const void* wp, const void* y, lo
 
 }  // namespace
 
+int msseg_k3_stats_finalize(const K3FinParams& f, int ncb, hipStream_t stream) {
+    hipLaunchKernelGGL(k3_stats_finalize_kernel, dim3(ncb), dim3(256), 0, stream, f);
+    MSSEG_CHECK_LAUNCH("k3_stats_finalize");
+    return MSSEG_OK;
+}
+
 // tools-only (not part of include/msseg.h): cycle counters written by the MSSEG_DIAG=5 build of the big-tile kernel
 extern "C" int msseg_debug_phase_cycles(unsigned long long* out8) {
     return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
@@ -868,6 +870,7 @@ static int k3_fwd_impl(const void* x, long long ldx, const void* wp, const float
     p.N = N; p.D = D; p.H = H; p.W = W; p.K = Cin; p.M = Cout;
     if (stats) {
         if (N > MSSEG_STATS_NMAX) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3: fused statistics need N <= %d", MSSEG_STATS_NMAX);
+        if (Cout > 64 * 16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3: fused statistics need Cout <= 1024 (one counter per cout block)");
         if (!scratch || ((uintptr_t)scratch & 255) || scratch_bytes < msseg_reduce_scratch_bytes())
             MSSEG_FAIL(MSSEG_EWORKSPACE, "conv3d_k3: fused statistics need a zero-initialised scratch of %zu bytes",
                        msseg_reduce_scratch_bytes());

@@ -25,6 +25,20 @@ struct K3ppParams {
 bool msseg_k3pp_eligible(const K3ppParams& p);
 int msseg_k3pp_launch(const K3ppParams& p, hipStream_t stream);
 
+// ---- second step of the fused conv-epilogue reductions (igemm_fwd.hip): one small block per cout block adds the
+// per-workgroup partial rows ws[(y * R + x) * L ..] in a fixed order and writes the per-(n, channel) results.  A
+// separate launch: the kernel boundary makes the partial rows visible without release/acquire fences (which would
+// write back / invalidate whole L2s at the end of every conv launch).
+struct K3FinParams {
+    const float* ws;
+    int R, N, coutb, M;        // partial rows per cout block, samples, cout block width, logical output channels
+    float* stats;              // [N][M][2]
+    const float* nb_stats;     // non-null: InstanceNorm-backward mode (see IgemmParams)
+    float nb_eps; long long nb_S;
+    float* nb_dgamma; float* nb_dbeta; int nb_acc;
+};
+int msseg_k3_stats_finalize(const K3FinParams& f, int ncb, hipStream_t stream);
+
 // ---- weight gradient (conv3d_k3_wgrad_pp.hip) ----
 struct K3WgParams {
     const void* pten; long long ldp;   // dy (channels M)
