@@ -147,15 +147,18 @@ int msseg_channel_stats(const void* x, long long ldx, float* stats, int N, long 
 int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
                            const void* residual, long long ldr, void* y, long long ldy, int N, long long S, int C,
                            float eps, float slope, int dtype, msseg_stream_t stream);
-/* backward, pass 1: red[n][c] = (sum dz, sum dz*xhat), dz = dy * lrelu'(y) (sign taken from the output y);
+/* backward, pass 1: red[n][c] = (sum dz, sum dz*xhat), dz = dy * lrelu'(z): the sign of the pre-activation z is taken
+ * from the forward output y, or -- y == NULL, layers without residual -- recomputed as x*rstd*gamma + beta - mean*...,
+ * which saves one tensor read (gamma/beta = the forward's affine parameters, nullable);
  * optional affine gradients dbeta[c] (+)= sum_n red[n][c][0], dgamma[c] (+)= sum_n red[n][c][1]. */
-int msseg_instnorm_act_bwd_reduce(const void* x, long long ldx, const float* stats, const void* y, long long ldy,
+int msseg_instnorm_act_bwd_reduce(const void* x, long long ldx, const float* stats, const float* gamma,
+                                  const float* beta, const void* y, long long ldy,
                                   const void* dy, long long lddy, float* red, float* dgamma, float* dbeta,
                                   int accumulate, int N, long long S, int C, float eps, float slope, void* scratch,
                                   size_t scratch_bytes, int dtype, msseg_stream_t stream);
-/* backward, pass 2: dx = rstd*gamma*(dz - red0/S - xhat*red1/S); dres (optional) = dz. */
-int msseg_instnorm_act_bwd_apply(const void* x, long long ldx, const float* stats, const float* gamma, const void* y,
-                                 long long ldy, const void* dy, long long lddy, const float* red, void* dx,
+/* backward, pass 2: dx = rstd*gamma*(dz - red0/S - xhat*red1/S); dres (optional) = dz.  y == NULL as above. */
+int msseg_instnorm_act_bwd_apply(const void* x, long long ldx, const float* stats, const float* gamma,
+                                 const float* beta, const void* y, long long ldy, const void* dy, long long lddy, const float* red, void* dx,
                                  long long lddx, void* dres, long long lddres, int N, long long S, int C, float eps,
                                  float slope, int dtype, msseg_stream_t stream);
 /* MaxPool3d(2) forward / backward (first maximum in scan order receives the gradient, as ATen). */

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(MODE == 1 ? RED_THREADS : 256) void instnorm_kernel
     long long r1 = r0 + p.rows_per_block;
     if (r1 > p.S) r1 = p.S;
     const T* xn = (const T*)p.x + (long long)n * p.S * p.ldx;
-    const T* yn = (MODE != 0) ? (const T*)p.y + (long long)n * p.S * p.ldy : nullptr;
+    const T* yn = (MODE != 0 && p.y != nullptr) ? (const T*)p.y + (long long)n * p.S * p.ldy : nullptr;
     T* yo = (MODE == 0) ? (T*)p.y + (long long)n * p.S * p.ldy : nullptr;
     const T* dyn = (MODE != 0) ? (const T*)p.dy + (long long)n * p.S * p.lddy : nullptr;
     const T* resn = (MODE == 0 && p.res) ? (const T*)p.res + (long long)n * p.S * p.ldr : nullptr;
@@ -436,13 +436,20 @@ __global__ __launch_bounds__(MODE == 1 ? RED_THREADS : 256) void instnorm_kernel
                     }
                 } else {
                     if constexpr (VEC) {
-                        Chunk<T> c; c.load(yn + r * p.ldy + gg * W);
                         Chunk<T> d; d.load(dyn + r * p.lddy + gg * W);
 #pragma unroll
-                        for (int e = 0; e < W; ++e) { yv[e] = c.v[e]; dv[e] = d.v[e]; }
+                        for (int e = 0; e < W; ++e) dv[e] = d.v[e];
+                        if (yn != nullptr) {
+                            Chunk<T> c; c.load(yn + r * p.ldy + gg * W);
+#pragma unroll
+                            for (int e = 0; e < W; ++e) yv[e] = c.v[e];
+                        } else {   // sign of the pre-activation, recomputed exactly as the forward formed it
+#pragma unroll
+                            for (int e = 0; e < W; ++e) yv[e] = xv[e] * sc[e] + sh[e];
+                        }
                     } else {
-                        yv[0] = DT<T>::ld(yn + r * p.ldy + gg);
                         dv[0] = DT<T>::ld(dyn + r * p.lddy + gg);
+                        yv[0] = (yn != nullptr) ? DT<T>::ld(yn + r * p.ldy + gg) : xv[0] * sc[0] + sh[0];
                     }
 #pragma unroll
                     for (int e = 0; e < W; ++e) {
@@ -854,17 +861,18 @@ int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, con
                return (launch_norm<bf16_t, 0>(p, N, vec, (hipStream_t)stream)));
 }
 
-int msseg_instnorm_act_bwd_reduce(const void* x, long long ldx, const float* stats, const void* y, long long ldy,
+int msseg_instnorm_act_bwd_reduce(const void* x, long long ldx, const float* stats, const float* gamma,
+                                  const float* beta, const void* y, long long ldy,
                                   const void* dy, long long lddy, float* red, float* dgamma, float* dbeta,
                                   int accumulate, int N, long long S, int C, float eps, float slope, void* scratch,
                                   size_t scratch_bytes, int dtype, msseg_stream_t stream) {
-    if (!x || !stats || !y || !dy || !red) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_bwd_reduce: null pointer");
+    if (!x || !stats || !dy || !red) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_bwd_reduce: null pointer");
     if (int rc = scratch_ok(scratch, scratch_bytes, "instnorm_act_bwd_reduce")) return rc;
     NormParams p{};
     p.counter = (unsigned int*)scratch;
     p.ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
     p.dgamma = dgamma; p.dbeta = dbeta; p.accumulate = accumulate;
-    p.x = x; p.ldx = ldx; p.stats = stats; p.y = (void*)y; p.ldy = ldy; p.dy = dy; p.lddy = lddy; p.red = red;
+    p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = gamma; p.beta = beta; p.y = (void*)y; p.ldy = ldy; p.dy = dy; p.lddy = lddy; p.red = red;
     p.S = S; p.C = C; p.eps = eps; p.slope = slope;
     const int esz = dtype == MSSEG_F32 ? 4 : 2;
     const bool vec = vec_ok(x, ldx, C, esz) && vec_ok(y, ldy, C, esz) && vec_ok(dy, lddy, C, esz);
@@ -872,13 +880,13 @@ int msseg_instnorm_act_bwd_reduce(const void* x, long long ldx, const float* sta
                return (launch_norm<bf16_t, 1>(p, N, vec, (hipStream_t)stream)));
 }
 
-int msseg_instnorm_act_bwd_apply(const void* x, long long ldx, const float* stats, const float* gamma, const void* y,
-                                 long long ldy, const void* dy, long long lddy, const float* red, void* dx,
+int msseg_instnorm_act_bwd_apply(const void* x, long long ldx, const float* stats, const float* gamma,
+                                 const float* beta, const void* y, long long ldy, const void* dy, long long lddy, const float* red, void* dx,
                                  long long lddx, void* dres, long long lddres, int N, long long S, int C, float eps,
                                  float slope, int dtype, msseg_stream_t stream) {
-    if (!x || !stats || !y || !dy || !red || !dx) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_bwd_apply: null pointer");
+    if (!x || !stats || !dy || !red || !dx) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_bwd_apply: null pointer");
     NormParams p{};
-    p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = gamma; p.y = (void*)y; p.ldy = ldy; p.dy = dy; p.lddy = lddy;
+    p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = gamma; p.beta = beta; p.y = (void*)y; p.ldy = ldy; p.dy = dy; p.lddy = lddy;
     p.red = (float*)red; p.dx = dx; p.lddx = lddx; p.dres = dres; p.lddres = lddres;
     p.S = S; p.C = C; p.eps = eps; p.slope = slope;
     const int esz = dtype == MSSEG_F32 ? 4 : 2;

@@ -57,8 +57,8 @@ SIGNATURES = {
     "msseg_deconv_k2s2_wgrad": ([_vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_channel_stats": ([_vp, _ll, _vp, _i, _ll, _i, _vp, _sz, _i, _vp], _i),
     "msseg_instnorm_act_fwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
-    "msseg_instnorm_act_bwd_reduce": ([_vp, _ll, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _ll, _i, _f, _f, _vp, _sz, _i, _vp], _i),
-    "msseg_instnorm_act_bwd_apply": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
+    "msseg_instnorm_act_bwd_reduce": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _ll, _i, _f, _f, _vp, _sz, _i, _vp], _i),
+    "msseg_instnorm_act_bwd_apply": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
     "msseg_maxpool2_fwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_maxpool2_bwd": ([_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_ncdhw_to_ndhwc": ([_vp, _i, _vp, _ll, _i, _i, _i, _ll, _vp], _i),
@@ -447,24 +447,27 @@ def instnorm_act_fwd(x, stats, gamma, beta, y, slope, eps=1e-5, residual=None):
 
 
 def instnorm_act_bwd(x, stats, gamma, y, dy, dx, slope, eps=1e-5, dres=None, dgamma=None, dbeta=None,
-                     accumulate=False):
+                     accumulate=False, beta=None):
     """dx (and dres) from dy; the affine gradients dgamma/dbeta (fp32 [C]) are written (or accumulated) by the
     reduce kernel's finalising block.  Returns red[N][C][2] = (sum dz, sum dz*xhat)."""
-    _need_gpu(x, stats, y, dy, dx)
+    _need_gpu(x, stats, dy, dx)
     N, S, Cc = _nsc(x)
     red = torch.empty(N, Cc, 2, dtype=torch.float32, device=x.device)
     sc = scratch(x.device)
-    _ck(lib().msseg_instnorm_act_bwd_reduce(_p(x), ld(x), _p(stats), _p(y), ld(y), _p(dy), ld(dy), _p(red),
+    _ck(lib().msseg_instnorm_act_bwd_reduce(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(y),
+                                            ld(y) if y is not None else 0, _p(dy), ld(dy), _p(red),
                                             _p(dgamma), _p(dbeta), int(accumulate), N, S, Cc, eps, slope, _p(sc),
                                             sc.numel(), dt(x), _stream()), "instnorm_act_bwd_reduce")
-    instnorm_act_bwd_apply(x, stats, gamma, y, dy, red, dx, slope, eps, dres)
+    instnorm_act_bwd_apply(x, stats, gamma, y, dy, red, dx, slope, eps, dres, beta)
     return red
 
 
-def instnorm_act_bwd_apply(x, stats, gamma, y, dy, red, dx, slope, eps=1e-5, dres=None):
-    _need_gpu(x, stats, y, dy, dx, red)
+def instnorm_act_bwd_apply(x, stats, gamma, y, dy, red, dx, slope, eps=1e-5, dres=None, beta=None):
+    """y None: the sign of the pre-activation is recomputed from x (layers without residual)"""
+    _need_gpu(x, stats, dy, dx, red)
     N, S, Cc = _nsc(x)
-    _ck(lib().msseg_instnorm_act_bwd_apply(_p(x), ld(x), _p(stats), _p(gamma), _p(y), ld(y), _p(dy), ld(dy), _p(red),
+    _ck(lib().msseg_instnorm_act_bwd_apply(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(y),
+                                           ld(y) if y is not None else 0, _p(dy), ld(dy), _p(red),
                                            _p(dx), ld(dx), _p(dres), ld(dres) if dres is not None else 0, N, S, Cc, eps,
                                            slope, dt(x), _stream()), "instnorm_act_bwd_apply")
     return red

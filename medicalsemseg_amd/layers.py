@@ -284,8 +284,10 @@ class InstNormAct:
         """red: reductions already produced by the kernel that made `da` (fused path) -> only the apply pass runs"""
         dy = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device)
         dres = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device) if want_dres else None
+        # without a residual the sign of the pre-activation is recomputed from y_raw: one tensor read less
+        a_in = a if want_dres else None
         if red is not None:
-            hip.instnorm_act_bwd_apply(y_raw, stats, self.gamma, a, da, red, dy, self.slope, self.eps, dres)
+            hip.instnorm_act_bwd_apply(y_raw, stats, self.gamma, a_in, da, red, dy, self.slope, self.eps, dres, self.beta)
             return (dy, dres) if want_dres else dy
         dg = db = None
         acc = False
@@ -293,7 +295,7 @@ class InstNormAct:
             dg, acc = _grad_buf(self.gamma)
             db, acc2 = _grad_buf(self.beta)
             assert acc == acc2
-        hip.instnorm_act_bwd(y_raw, stats, self.gamma, a, da, dy, self.slope, self.eps, dres, dg, db, acc)
+        hip.instnorm_act_bwd(y_raw, stats, self.gamma, a_in, da, dy, self.slope, self.eps, dres, dg, db, acc, self.beta)
         return (dy, dres) if want_dres else dy
 
 
