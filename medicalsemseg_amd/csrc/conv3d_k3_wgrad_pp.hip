@@ -27,7 +27,7 @@ namespace {
 
 constexpr int TD = 4, TH = 4, TW = 16;
 constexpr int PD = TD + 2, PH = TH + 2, PW = TW + 2;
-constexpr int PWP = 24;                   // LDS row pitch of one halo line (18 voxels + 6 unused rows)
+constexpr int PWP = PW;                   // LDS row pitch of one halo line
 constexpr int HV = PD * PH * PWP;         // 864 LDS rows of the x halo image
 constexpr int TV = TD * TH * TW;          // 256 tile voxels
 constexpr int Q_BYTES = HV * 64;
@@ -36,7 +36,7 @@ constexpr int GRP_BYTES = Q_BYTES + P_BYTES;
 constexpr int NIQ = (HV + 15) / 16;       // DMA wave-instructions per image (16 rows of 64 B each)
 constexpr int NIP = TV / 16;
 constexpr int NIQ_W = (NIQ + 3) / 4, NIP_W = NIP / 4;   // per wave of a group
-constexpr int NKS = TV / 32;
+constexpr int NKS = TV / 16;                 // k-steps: one 16-voxel tile row each
 constexpr int TAPW = 7;
 constexpr int NTHREADS = 512;
 constexpr int SLAB_FLOATS = 27 * 32 * 32;
@@ -50,6 +50,7 @@ MSSEG_DEVFN void glds16(const void* g, void* l) {
 }
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // the pointer stays an LDS-address-space pointer up to the builtin so that constant offsets fold into the
 // instruction's 16-bit offset field (one address VGPR per lane-dependent base instead of one per read)
@@ -65,9 +66,8 @@ MSSEG_DEVFN u32x4_t tr_frag(lds_u8* r0, lds_u8* r1) {
 
 struct TileCo { int n, d0, h0, w0; };
 
-// LDS halo row of tile voxel 32*ks + 8*g + 4*i + qr, without the per-lane part ((g>>1)*PWP + 8*(g&1) + 4*i + qr):
-// always a multiple of 16
-constexpr int ks_row(int ks) { return ((ks / 2) * PH + (2 * ks) % 4) * PWP; }
+// LDS halo row of the first voxel of tile row ks (td = ks / TH, th = ks % TH)
+constexpr int ks_row(int ks) { return ((ks / TH) * PH + ks % TH) * PWP; }
 
 template <int TIMING>
 __global__ __launch_bounds__(NTHREADS, 1) void k3wg_pp_kernel(const K3WgParams p) {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3wg_pp_kernel(const K3WgParams p
     // Lane l of wave-instruction `it` fills row it*16 + (l >> 2), physical 16-byte slot l & 3, with the logical chunk
     // (l & 3) ^ 2*bit3(row); bit 3 of the row is bit 5 of the lane for every `it`.
     const int lrow = lane >> 2;
-    const int lchunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
+    const int lchunk = lane & 3;
     constexpr unsigned SKIP = 0xffffffffu;   // q_off of an unused LDS row
     unsigned q_off[NIQ_W], p_off[NIP_W];
 #pragma unroll
@@ -161,53 +161,42 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3wg_pp_kernel(const K3WgParams p
         }
     };
 
-    // ---- MFMA role: precomputed per-lane read addresses.  lane = 16*g + 4*qr + pc reads, for half-fragment i, the
-    // row 32*ks + 8*g + 4*i + qr (8 voxels per 16-lane group after the transposing read) at channels 4*pc.. of a
-    // 16-channel tile.  The physical 32-byte half of logical tile `t` on a row is t ^ bit3(row).
-    // Halo row of that voxel under tap t = ks_row(ks) + tap offset + lane part; ks_row(ks) is a multiple of 16, so the
-    // swizzle is folded, per tap of this wave, into q_rd[tt][i][b] once.
-    const int g = lane >> 4, qr = (lane >> 2) & 3, pc = lane & 3;
+    // ---- MFMA role (v_mfma_f32_32x32x16_bf16: one instruction = one tap x 16 voxels x the whole 32 x 32 block).
+    // Operand layout: lane l holds 8 consecutive voxels (k = 8*(l>>5) ..) of channel l & 31.  With the transposing
+    // read, 16-lane group G = l >> 4 supplies rows (voxels) 8*(G>>1) + 4*i + qr of channel tile G & 1 at channels
+    // 4*pc..; the 32 lanes of one half-wave then read 4 consecutive full 64-byte rows: conflict-free without swizzle.
+    // A 16-cycle-issue budget per 32-cycle MFMA leaves room for the fragment reads (the 16x16x32 form, which holds the
+    // vector issue port for 8 of its 16 cycles, ran this loop at 22 cycles per MFMA).
+    const int G = lane >> 4, qr = (lane >> 2) & 3, pc = lane & 3;
     const unsigned qbase = grp * GRP_BYTES, pbase = qbase + Q_BYTES;
-    unsigned p_rd[2][2], q_rd[TAPW][2][2];
+    unsigned p_rd[2], q_rd[TAPW][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int prow = 8 * g + 4 * i + qr;   // + 32*ks : bit 3 of the row is g & 1
-#pragma unroll
-        for (int a = 0; a < 2; ++a) p_rd[i][a] = pbase + prow * 64 + ((a ^ (g & 1)) << 5) + pc * 8;
-        const int lrowq = (g >> 1) * PWP + 8 * (g & 1) + 4 * i + qr;
+        const int lrow = 8 * (G >> 1) + 4 * i + qr;
+        p_rd[i] = pbase + lrow * 64 + ((G & 1) << 5) + pc * 8;
 #pragma unroll
         for (int tt = 0; tt < TAPW; ++tt) {
             int tap = wq * TAPW + tt;
             if (tap > 26) tap = 26;             // wave 3 owns 6 taps: its 7th slot repeats tap 26 and is discarded
-            const int row = ((tap / 9) * PH + ((tap / 3) % 3)) * PWP + (tap % 3) + lrowq;
-            const int s = (row >> 3) & 1;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) q_rd[tt][i][b] = qbase + row * 64 + ((b ^ s) << 5) + pc * 8;
+            const int row = ((tap / 9) * PH + ((tap / 3) % 3)) * PWP + (tap % 3) + lrow;
+            q_rd[tt][i] = qbase + row * 64 + ((G & 1) << 5) + pc * 8;
         }
     }
 
-    f32x4_t acc[TAPW][2][2];
+    f32x16_t acc[TAPW];
 #pragma unroll
     for (int t = 0; t < TAPW; ++t)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
     auto compute = [&]() {
         constexpr int NSTEP = NKS * TAPW;
-        constexpr int QA = 1;                 // x fragments in flight ahead of their MFMAs (steps of 4 MFMAs)
-        u32x4_t pf[2][2], qf[QA + 1][2];
-        auto ldp = [&](int ks) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) pf[ks & 1][a] = tr_frag(smem3 + p_rd[0][a] + ks * 2048, smem3 + p_rd[1][a] + ks * 2048);
-        };
+        constexpr int QA = 2;                 // x fragments in flight ahead of their MFMA
+        u32x4_t pf[2], qf[QA + 1];
+        auto ldp = [&](int ks) { pf[ks & 1] = tr_frag(smem3 + p_rd[0] + ks * 1024, smem3 + p_rd[1] + ks * 1024); };
         auto ldq = [&](int s) {     // s = ks * TAPW + tt
             const int ks = s / TAPW, tt = s % TAPW;
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-                qf[s % (QA + 1)][b] = tr_frag(smem3 + q_rd[tt][0][b] + ks_row(ks) * 64,
-                                       smem3 + q_rd[tt][1][b] + ks_row(ks) * 64);
+            qf[s % (QA + 1)] = tr_frag(smem3 + q_rd[tt][0] + ks_row(ks) * 64, smem3 + q_rd[tt][1] + ks_row(ks) * 64);
         };
         ldp(0);
 #pragma unroll
@@ -220,10 +209,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3wg_pp_kernel(const K3WgParams p
                 if (s + QA < NSTEP) ldq(s + QA);
                 if (tt == 0 && ks + 1 < NKS) ldp(ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) mma_chunk<bf16_t>(acc[tt][a][b], pf[ks & 1][a], qf[s % (QA + 1)][b]);
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, pf[ks & 1]),
+                                                                  __builtin_bit_cast(bf16x8_t, qf[s % (QA + 1)]),
+                                                                  acc[tt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -259,20 +247,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3wg_pp_kernel(const K3WgParams p
     }
 
     // ---- group 1 -> LDS, group 0 adds and writes the workgroup's slab
+    // 32x32 accumulator layout: register e of lane l = row (cout) (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), column (cin) l & 31
     float* xch = (float*)smem;
-    const int r = lane & 15, q = lane >> 4;
+    const int col = lane & 31, rb = 4 * (lane >> 5);
     const int tap0 = wq * TAPW;
     if (grp == 1) {
 #pragma unroll
         for (int tt = 0; tt < TAPW; ++tt) {
             if (tap0 + tt < 27) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            xch[((tap0 + tt) * 32 + a * 16 + q * 4 + e) * 32 + b * 16 + r] = acc[tt][a][b][e];
+                for (int e = 0; e < 16; ++e)
+                    xch[((tap0 + tt) * 32 + (e & 3) + 8 * (e >> 2) + rb) * 32 + col] = acc[tt][e];
             }
         }
     }
@@ -283,14 +268,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3wg_pp_kernel(const K3WgParams p
         for (int tt = 0; tt < TAPW; ++tt) {
             if (tap0 + tt < 27) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int idx = ((tap0 + tt) * 32 + a * 16 + q * 4 + e) * 32 + b * 16 + r;
-                            slab[idx] = acc[tt][a][b][e] + xch[idx];
-                        }
+                for (int e = 0; e < 16; ++e) {
+                    const int idx = ((tap0 + tt) * 32 + (e & 3) + 8 * (e >> 2) + rb) * 32 + col;
+                    slab[idx] = acc[tt][e] + xch[idx];
+                }
             }
         }
     }
