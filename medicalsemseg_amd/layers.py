@@ -11,6 +11,8 @@ covers the whole network and every buffer / accumulation is decided here, not by
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -99,6 +101,78 @@ class PackedCache:
         return rec["dst"]
 
 
+class _WgradSide:
+    """Weight-gradient kernels on a second HIP stream.
+
+    In the backward pass only the input-gradient chain is serial; every weight gradient depends on tensors that exist
+    when its layer is reached and is needed only by the optimizer.  The whole-network backward functions open a
+    section (`begin`), the layers then issue their wgrad kernels through `run` on the side stream (after the main
+    stream's work so far), and `join` makes the main stream wait for them.  The full-chip wgrad kernels of the
+    high-resolution levels then overlap the many small kernels of the deep levels instead of queueing behind them.
+    The side stream owns the wgrad workspace (all wgrad launches are serial on it); tensors handed to it are kept
+    alive until the join."""
+
+    INLINE, SIDE, DEFER = 0, 1, 2
+
+    def __init__(self):
+        self.streams = {}
+        self.active = None
+        self.mode = self.INLINE
+        self.keep = []
+        self.deferred = []
+
+    def begin(self, device):
+        # Measured on MI355X (round 1, UNet 96^3 B=2): 5.38 ms/step with the side stream vs 5.22 ms without -- the
+        # persistent wgrad workgroups take a CU's whole register file, so nothing co-resides and the small kernels only
+        # queue behind them.  Kept as an opt-in experiment.
+        if not torch.cuda.is_available() or not os.environ.get("MSSEG_WGRAD_STREAM"):
+            return
+        st = self.streams.get(device)
+        if st is None:
+            st = self.streams[device] = torch.cuda.Stream(device=device)
+        self.active = st
+        self.mode = self.INLINE
+
+    def set_mode(self, mode):
+        """INLINE: on the calling stream (full-chip layers with nothing small to overlap); SIDE: on the side stream
+        right away (small layers); DEFER: collected and issued to the side stream by flush() -- full-chip wgrads that
+        should run under the small kernels of the deep levels rather than against the next full-chip dgrad."""
+        if self.active is not None:
+            self.mode = mode
+
+    def _issue(self, fn):
+        st = self.active
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            fn()
+
+    def run(self, fn, *tensors):
+        if self.active is None or self.mode == self.INLINE:
+            return fn()
+        self.keep.extend(tensors)
+        if self.mode == self.DEFER:
+            self.deferred.append(fn)
+        else:
+            self._issue(fn)
+
+    def flush(self):
+        if self.active is not None:
+            for fn in self.deferred:
+                self._issue(fn)
+        self.deferred = []
+
+    def join(self):
+        self.flush()
+        st, self.active = self.active, None
+        self.mode = self.INLINE
+        if st is not None:
+            torch.cuda.current_stream().wait_stream(st)
+        self.keep.clear()
+
+
+WGRAD_SIDE = _WgradSide()
+
+
 def _grad_buf(p: torch.nn.Parameter):
     """(tensor to write the gradient into, accumulate?)"""
     if p.grad is None:
@@ -148,9 +222,9 @@ class Conv3:
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
             if self._gather(dtype):
-                hip.conv3d_gather_wgrad(x, dy, g, self.cin, self.cout, 3, 1, 1, acc)
+                WGRAD_SIDE.run(lambda: hip.conv3d_gather_wgrad(x, dy, g, self.cin, self.cout, 3, 1, 1, acc), x, dy)
             else:
-                hip.conv3d_k3_wgrad(x, dy, g, self.cin, self.cout, acc)
+                WGRAD_SIDE.run(lambda: hip.conv3d_k3_wgrad(x, dy, g, self.cin, self.cout, acc), x, dy)
         if self.b is not None and self.b.requires_grad:
             g, acc = _grad_buf(self.b)
             if bias_grad_is_zero:
@@ -216,9 +290,9 @@ class Conv1:
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
             if self._gather(dtype):
-                hip.conv3d_gather_wgrad(x, dy[..., :self.cout], g, self.cin, self.cout, 1, 1, 0, acc)
+                WGRAD_SIDE.run(lambda: hip.conv3d_gather_wgrad(x, dy[..., :self.cout], g, self.cin, self.cout, 1, 1, 0, acc), x, dy)
             else:
-                hip.conv3d_k1_wgrad(x, dy[..., :self.cout], g, self.cin, self.cout, acc)
+                WGRAD_SIDE.run(lambda: hip.conv3d_k1_wgrad(x, dy[..., :self.cout], g, self.cin, self.cout, acc), x, dy)
         if self.b is not None and self.b.requires_grad:
             g, acc = _grad_buf(self.b)
             hip.channel_sum(dy[..., :self.cout], g, acc)
@@ -254,7 +328,7 @@ class Deconv2:
         dtype = x.dtype
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
-            hip.deconv_k2s2_wgrad(x, dy, g, self.cin, self.cout, acc)
+            WGRAD_SIDE.run(lambda: hip.deconv_k2s2_wgrad(x, dy, g, self.cin, self.cout, acc), x, dy)
         if self.b is not None and self.b.requires_grad:
             g, acc = _grad_buf(self.b)
             hip.channel_sum(dy, g, acc)

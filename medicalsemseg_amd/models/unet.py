@@ -18,7 +18,7 @@ from typing import Sequence
 import torch
 import torch.nn as nn
 
-from .. import hip
+from .. import hip, layers
 from ..layers import Conv1, Conv3, ConvNormAct, Deconv2, InstNormAct, maxpool_fwd
 
 UNET_FEATURES = {"UNet": (32, 32, 64, 128, 256, 32), "UNetSmall": (16, 16, 32, 64, 128, 16)}
@@ -179,11 +179,24 @@ class _UNetFn(torch.autograd.Function):
         dev = dlogits.device
         dl = torch.zeros(N, D, H, W, LOGIT_LD, dtype=T, device=dev)
         hip.to_channels_last(dlogits.contiguous(), dl[..., :C])
+        layers.WGRAD_SIDE.begin(dev)
+        try:
+            return _UNetFn._backward_body(ctx, net, saved, dl, f, n_in)
+        finally:
+            layers.WGRAD_SIDE.join()
+
+    @staticmethod
+    def _backward_body(ctx, net, saved, dl, f, n_in):
+        side = layers.WGRAD_SIDE
+        side.set_mode(side.DEFER)
         g = net._final.bwd(ctx.last, dl, True, dy_channels=LOGIT_LD)
         skip_grads = [None] * 4
         for j in range(3, -1, -1):  # decoder levels 0..3 in reverse order of execution
             up, c0, c1 = net._dec[j]
             lvl = 3 - j
+            if lvl == 2:   # the deep levels begin: their small kernels run under the deferred full-chip wgrads
+                side.flush()
+                side.set_mode(side.SIDE)
             up_in, s0, s1 = saved["dec"][j]
             g, red = c1.bwd(s1, g, True, next_saved=s0, next_cna=c0)
             dcat = c0.bwd(s0, g, True, red=red)
@@ -193,6 +206,8 @@ class _UNetFn(torch.autograd.Function):
         for lvl in range(4, -1, -1):
             c0, c1 = net._enc[lvl]
             s0, s1 = saved["enc"][lvl]
+            if lvl == 1:
+                side.set_mode(side.INLINE)
             if lvl < 4:
                 # gradient of the skip (written by the decoder) + max-pool path from the level below
                 x_l = s1[3]
