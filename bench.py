@@ -241,15 +241,30 @@ def main():
     }
     if rank == 0:
         summ = hip.TIMER.summary()
-        k = summ.get("conv3d_k3_fwd/v0")   # the large-layer variant (>= 48^3 grids): 82 % of the conv FLOPs
+        # dominant kernel = the conv3d k3 forward / input-gradient kernel of the 32-channel stages (the 96^3 and 48^3
+        # levels): v3 = LDS-DMA ping-pong kernel (conv3d_k3_pp.hip); falls back to the generic big-tile kernel (v0)
+        kid = "conv3d_k3_fwd/v3" if "conv3d_k3_fwd/v3" in summ else "conv3d_k3_fwd/v0"
+        k = summ.get(kid)
         if k:
             tf = k["flops"] / (k["total_ms"] * 1e-3) / 1e12
             peak = MFMA_PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
             allk = [v for kk, v in summ.items() if kk.startswith("conv3d_k3_fwd")]
-            res["roofline"] = {"bound": "mfma", "kernel": "igemm_fwd_kernel<bf16,27,DIRECT,STORE,4,8,16,8,NT=2> "
-                                                            "(conv3d k3 fwd + dgrad, 4x8x16 tiles)",
+            name = ("k3pp_kernel<STATS> (conv3d k3 fwd + dgrad, bf16, 32-channel stages, 4x4x16 tiles, LDS-DMA ping-pong)"
+                    if kid.endswith("v3") else
+                    "igemm_fwd_kernel<27,DIRECT,STORE,4,8,16,8,NT=2> (conv3d k3 fwd + dgrad, 4x8x16 tiles)")
+            traffic = None
+            try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE x2 + WRITE_SIZE
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")) as fh:
+                    tj = json.load(fh)
+                ent = tj.get(kid)
+                if ent and args.dtype == "bf16" and args.size == ent.get("size") and args.batch == ent.get("batch"):
+                    traffic = ent["hbm_bytes_per_launch"]
+            except (OSError, ValueError):
+                pass
+            res["roofline"] = {"bound": "mfma", "kernel": name,
                                "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                               "traffic": None, "launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
+                               "traffic": traffic, "launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
+                               "flops_per_launch_avg": round(k["flops"] / k["launches"]),
                                "share_of_step": round((k["total_ms"] / instr_steps) / (dt * 1e3 / args.steps), 3),
                                "all_k3_variants_tflops": round(sum(v["flops"] for v in allk) / (sum(v["total_ms"] for v in allk) * 1e-3) / 1e12, 2)}
             w = summ.get("conv3d_k3_wgrad")

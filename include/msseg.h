@@ -71,6 +71,10 @@ int msseg_cout_block(int M);
 int msseg_conv3d_k3_cout_block(int N, int D, int H, int W, int Cout);
 /* tile variant it will use: 0 = 4x8x16-voxel tiles / 8 waves (the MFMA-bound large layers), 1 = 4x4x8, 2 = 2x4x8 */
 int msseg_conv3d_k3_variant(int N, int D, int H, int W, int Cout);
+/* kernel msseg_conv3d_k3_fwd / _dgrad_inbwd will run for this problem (16-byte aligned, dense operands):
+ * 0/1/2 = generic implicit-GEMM tile configurations (as msseg_conv3d_k3_variant), 3 = the LDS-DMA ping-pong kernel
+ * (bf16, 32 input channels per stage, large grids).  For per-kernel timing and reporting only. */
+int msseg_conv3d_k3_kernel(int N, int D, int H, int W, int Cin, int Cout, int dtype);
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolutions (forward-shaped).  y = conv(x, W) + bias.

@@ -827,6 +827,18 @@ int msseg_conv3d_k3_variant(int N, int D, int H, int W, int Cout) {
     return cfg;
 }
 
+int msseg_conv3d_k3_kernel(int N, int D, int H, int W, int Cin, int Cout, int dtype) {
+    int cfg, cb;
+    k3_plan(N, D, H, W, Cout, &cfg, &cb);
+    if (dtype == MSSEG_BF16 && cb == 32) {
+        K3ppParams pp{};
+        pp.x = (const void*)256; pp.y = (void*)256; pp.ldx = Cin; pp.ldy = Cout;
+        pp.N = N; pp.D = D; pp.H = H; pp.W = W; pp.K = Cin; pp.M = Cout;
+        if ((Cin % 8) == 0 && (Cout % 4) == 0 && msseg_k3pp_eligible(pp)) return 3;
+    }
+    return cfg;
+}
+
 static int k3_fwd_impl(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy, int N,
                        int D, int H, int W, int Cin, int Cout, float* stats, void* scratch, size_t scratch_bytes,
                        const void* nb_y, long long nb_ldy, const void* nb_a, long long nb_lda, const float* nb_stats,

@@ -33,6 +33,7 @@ SIGNATURES = {
     "msseg_cout_block": ([_i], _i),
     "msseg_conv3d_k3_cout_block": ([_i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_variant": ([_i, _i, _i, _i, _i], _i),
+    "msseg_conv3d_k3_kernel": ([_i, _i, _i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_reduce_scratch_bytes": ([], _sz),
     "msseg_conv3d_k3_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll, _vp, _f, _f, _vp,
@@ -302,7 +303,7 @@ def conv3d_k3(x, wp, bias, y, cin, cout, stats=None):
                                       _p(sc), sc.numel() if sc is not None else 0, dt(x), _stream()), "conv3d_k3_fwd")
     key = "conv3d_k3_fwd"
     if TIMER.enabled:
-        key += "/v%d" % lib().msseg_conv3d_k3_variant(N, D, H, W, cout)
+        key += "/v%d" % lib().msseg_conv3d_k3_kernel(N, D, H, W, cin, cout, dt(x))
     TIMER.launch(key, 2.0 * nv * 27 * cin * cout, nv * (cin + cout) * esz + 27 * cin * cout * esz, go)
     return y
 
@@ -325,7 +326,7 @@ def conv3d_k3_dgrad_inbwd(dy, wp, da, cin, cout, yraw, act, fwd_stats, slope, ep
                                               _stream()), "conv3d_k3_dgrad_inbwd")
     key = "conv3d_k3_fwd"
     if TIMER.enabled:
-        key += "/v%d" % lib().msseg_conv3d_k3_variant(N, D, H, W, cout)
+        key += "/v%d" % lib().msseg_conv3d_k3_kernel(N, D, H, W, cin, cout, dt(dy))
     TIMER.launch(key, 2.0 * nv * 27 * cin * cout, nv * (cin + 3 * cout) * esz + 27 * cin * cout * esz, go)
     return red
 
