@@ -950,6 +950,12 @@ int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const 
     if (OD < 1 || OH < 1 || OW < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: empty output");
     const long long NV = (long long)N * OD * OH * OW;
     if (NV > 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather: too many voxels");
+    if (msseg_stem_eligible(dtype, Cin, Cout, k, s, pd, ldx, ldy, y)) {
+        StemParams sp{};
+        sp.x = x; sp.ldx = ldx; sp.wp = wp; sp.bias = bias; sp.y = y; sp.ldy = ldy;
+        sp.N = N; sp.D = ID; sp.H = IH; sp.W = IW; sp.M = Cout;
+        return msseg_stem_fwd_launch(sp, (hipStream_t)stream);
+    }
     IgemmParams p{};
     p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy;
     p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = Cin * k * k * k; p.M = Cout;
@@ -957,6 +963,25 @@ int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const 
     p.cin = Cin; p.k = k; p.s = s; p.p = pd;
     return dtype == MSSEG_F32 ? launch_flat<float, SRC_GATHER, EPI_STORE>(p, (hipStream_t)stream)
                               : launch_flat<bf16_t, SRC_GATHER, EPI_STORE>(p, (hipStream_t)stream);
+}
+
+int msseg_conv3d_stem_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                          int N, int D, int H, int W, int Cout, float* stats, void* scratch, size_t scratch_bytes,
+                          int dtype, msseg_stream_t stream) {
+    if (!x || !wp || !y || N < 1 || D < 1 || H < 1 || W < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem: bad args");
+    if (!msseg_stem_eligible(dtype, 1, Cout, 3, 1, 1, ldx, ldy, y))
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem: bf16, Cout %% 32 == 0 (<= 256), 8-byte aligned output rows only");
+    StemParams sp{};
+    sp.x = x; sp.ldx = ldx; sp.wp = wp; sp.bias = bias; sp.y = y; sp.ldy = ldy;
+    sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.M = Cout;
+    if (stats) {
+        if (N > MSSEG_STATS_NMAX) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem: fused statistics need N <= %d", MSSEG_STATS_NMAX);
+        if (!scratch || ((uintptr_t)scratch & 255) || scratch_bytes < msseg_reduce_scratch_bytes())
+            MSSEG_FAIL(MSSEG_EWORKSPACE, "conv3d_stem: fused statistics need a scratch of %zu bytes", msseg_reduce_scratch_bytes());
+        sp.stats = stats;
+        sp.stats_ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+    }
+    return msseg_stem_fwd_launch(sp, (hipStream_t)stream);
 }
 
 int msseg_deconv_k2s2_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,

@@ -575,6 +575,22 @@ int msseg_conv3d_gather_wgrad(const void* x, long long ldx, const void* dy, long
     const long long NV = (long long)N * OD * OH * OW;
     if (OD < 1 || OH < 1 || OW < 1 || NV > 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: bad shape");
     const int KT = k * k * k;
+    if (msseg_stem_eligible(dtype, Cin, Cout, k, s, pd, ldx, lddy, dy) && (lddy % 8) == 0 &&
+        workspace_bytes >= (size_t)8 * 4096 * (Cout / 32)) {
+        StemWgParams sp{};
+        sp.x = x; sp.ldx = ldx; sp.dy = dy; sp.lddy = lddy; sp.N = N; sp.D = ID; sp.H = IH; sp.W = IW; sp.M = Cout;
+        int gx = msseg_stem_wgrad_grid(sp);
+        const long long fit = (long long)(workspace_bytes / ((size_t)4096 * (Cout / 32)));
+        if (gx > fit) gx = (int)(fit & ~7LL);
+        sp.slabs = (float*)workspace;
+        int rc = msseg_stem_wgrad_launch(sp, gx, (hipStream_t)stream);
+        if (rc) return rc;
+        ReduceParams rq{};
+        rq.dw = dw; rq.M = Cout; rq.M0 = Cout; rq.T = 1; rq.K = KT; rq.K0 = 1;
+        rq.s_m0 = KT; rq.s_k1 = 1; rq.s_k0 = KT; rq.accumulate = accumulate;
+        rq.slabs = sp.slabs; rq.mblks = Cout / 32; rq.kblks = 1; rq.nslots = gx; rq.cbw = 32;
+        return launch_reduce(rq, (hipStream_t)stream);
+    }
     WgradParams p{};
     p.pten = dy; p.ldp = lddy; p.qten = x; p.ldq = ldx;
     p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.M = Cout; p.K = Cin * KT;

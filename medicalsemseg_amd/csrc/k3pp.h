@@ -50,3 +50,23 @@ struct K3WgParams {
 bool msseg_k3wg_pp_eligible(const K3WgParams& p);
 int msseg_k3wg_pp_grid(const K3WgParams& p);      // workgroups per block pair (= slabs per pair)
 int msseg_k3wg_pp_launch(const K3WgParams& p, int gx, hipStream_t stream);
+
+// ---- one-input-channel stem convolution (stem_conv.hip) ----
+struct StemParams {
+    const void* x; long long ldx;     // [N, D, H, W, 1] bf16
+    const void* wp;                   // packed image, K = 27, cout block 32
+    const float* bias;
+    void* y; long long ldy;
+    int N, D, H, W, M;
+    float* stats; float* stats_ws;    // optional fused statistics (partial rows -> msseg_k3_stats_finalize)
+};
+struct StemWgParams {
+    const void* x; long long ldx;
+    const void* dy; long long lddy;
+    float* slabs;                     // [cout block][workgroup][32][32] fp32
+    int N, D, H, W, M;
+};
+bool msseg_stem_eligible(int dtype, int Cin, int Cout, int k, int s, int pd, long long ldx, long long ldy, const void* y);
+int msseg_stem_fwd_launch(const StemParams& p, hipStream_t stream);
+int msseg_stem_wgrad_grid(const StemWgParams& p);
+int msseg_stem_wgrad_launch(const StemWgParams& p, int gx, hipStream_t stream);

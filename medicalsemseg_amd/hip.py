@@ -47,6 +47,7 @@ SIGNATURES = {
     "msseg_layernorm_param_grad": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _i, _ll, _i, _vp, _sz, _i, _vp], _i),
     "msseg_gelu_fwd": ([_vp, _vp, _ll, _i, _vp], _i),
     "msseg_gelu_bwd": ([_vp, _vp, _vp, _ll, _i, _vp], _i),
+    "msseg_conv3d_stem_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_k1_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_gather_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_deconv_k2s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -344,6 +345,16 @@ def conv3d_gather(x, wp, bias, y, cin, cout, k, s, p):
     N, D, H, W = x.shape[:4]
     _ck(lib().msseg_conv3d_gather_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, k, s, p,
                                       dt(x), _stream()), "conv3d_gather_fwd")
+    return y
+
+
+def conv3d_stem(x, wp, bias, y, cout, stats=None):
+    """conv3d k3 p1 of a ONE-channel volume (bf16, cout % 32 == 0) with optional fused InstanceNorm statistics"""
+    _need_gpu(x, wp, y)
+    N, D, H, W = x.shape[:4]
+    sc = scratch(x.device) if stats is not None else None
+    _ck(lib().msseg_conv3d_stem_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cout, _p(stats), _p(sc),
+                                    sc.numel() if sc is not None else 0, dt(x), _stream()), "conv3d_stem_fwd")
     return y
 
 

@@ -204,7 +204,13 @@ class Conv3:
         stats = None
         if self._gather(dtype):
             wp = self.cache.get(self.w, dtype, "g", lambda: hip.pack_conv_gather(self.w.detach(), dtype))
-            hip.conv3d_gather(x, wp, self.b, y, self.cin, self.cout, 3, 1, 1)
+            if self.cin == 1 and dtype == torch.bfloat16 and self.cout % 32 == 0 and self.cout <= 256:
+                # the one-channel stem: dedicated kernel with the statistics fused
+                if want_stats and x.shape[0] <= 8:
+                    stats = torch.empty(x.shape[0], self.cout, 2, dtype=torch.float32, device=x.device)
+                hip.conv3d_stem(x, wp, self.b, y, self.cout, stats)
+            else:
+                hip.conv3d_gather(x, wp, self.b, y, self.cin, self.cout, 3, 1, 1)
         else:
             vol = tuple(x.shape[:4])
             wp = self.cache.get(self.w, dtype, ("f", vol), lambda: hip.pack_conv_k3(self.w.detach(), dtype, vol=vol))

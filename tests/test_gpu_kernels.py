@@ -125,6 +125,47 @@ def test_conv3d_gather(dtype, cin, cout, k, s, p, sp):
     check(dw, wr.grad, dtype, "gather wgrad")
 
 
+@pytest.mark.parametrize("cout,sp,N", [(32, (16, 16, 16), 2), (64, (10, 13, 21), 3), (32, (33, 20, 48), 2)])
+def test_conv3d_stem(cout, sp, N):
+    """one-input-channel stem kernels (bf16): forward + fused InstanceNorm statistics + weight gradient, on grids that
+    are not tile multiples"""
+    from medicalsemseg_amd import hip
+    dev = _dev()
+    dtype = torch.bfloat16
+    x = gen(N, 1, *sp, seed=1)
+    w = gen(cout, 1, 3, 3, 3, seed=2, scale=27 ** -0.5)
+    b = gen(cout, seed=3)
+    xr, wr = rnd(dtype, x, w)
+    wr.requires_grad_(True)
+    yref = F.conv3d(xr, wr, b, padding=1)
+    dy = gen(*yref.shape, seed=4)
+    dyr = rnd(dtype, dy)
+    yref.backward(dyr)
+    xg = cl(x, dtype, dev)
+    wp = hip.pack_conv_gather(w.to(dev), dtype)
+    y = torch.empty(N, *sp, cout, dtype=dtype, device=dev)
+    stats = torch.full((N, cout, 2), float("nan"), device=dev)
+    hip.conv3d_stem(xg, wp, b.to(dev), y, cout, stats)
+    check(ncdhw(y), yref.detach(), dtype, "stem fwd")
+    yf = y.float().reshape(N, -1, cout)
+    ref = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)
+    assert float((stats - ref).abs().max()) / float(ref.abs().max()) < 1e-5
+    s2 = torch.empty_like(stats)
+    y2 = torch.empty_like(y)
+    hip.conv3d_stem(xg, wp, b.to(dev), y2, cout, s2)
+    assert torch.equal(y2, y) and torch.equal(s2, stats)
+    # the gather entry points route to the same kernels
+    y3 = torch.empty_like(y)
+    hip.conv3d_gather(xg, wp, b.to(dev), y3, 1, cout, 3, 1, 1)
+    assert torch.equal(y3, y)
+    dw = torch.empty(cout, 1, 3, 3, 3, device=dev)
+    hip.conv3d_gather_wgrad(xg, cl(dy, dtype, dev), dw, 1, cout, 3, 1, 1)
+    check(dw, wr.grad, dtype, "stem wgrad")
+    dw2 = dw.clone()
+    hip.conv3d_gather_wgrad(xg, cl(dy, dtype, dev), dw2, 1, cout, 3, 1, 1, True)
+    check(dw2, 2 * wr.grad, dtype, "stem wgrad accumulate")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,sp", [(32, 32, (8, 8, 8)), (256, 128, (3, 3, 3)), (96, 48, (6, 6, 6)), (48, 48, (4, 6, 10))])
 def test_deconv_k2s2(dtype, cin, cout, sp):
