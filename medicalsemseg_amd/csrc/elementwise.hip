@@ -702,26 +702,31 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const msseg_pack_job* __restrict__ jobs) {
-    constexpr int EPC = DT<T>::EPC;
+    constexpr unsigned EPC = DT<T>::EPC;
     const msseg_pack_job j = jobs[blockIdx.y];
     T* dst = (T*)j.dst;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < j.total; i += (long long)gridDim.x * 256) {
-        long long t = i;
-        const int e = (int)(t % EPC); t /= EPC;
-        const int col = (int)(t % j.cout_block); t /= j.cout_block;
-        const int q = (int)(t % 4); t /= 4;
-        const int tap = (int)(t % j.T); t /= j.T;
-        const int kb = (int)(t % j.nkb);
-        const int cb = (int)(t / j.nkb);
-        const int m = cb * j.cout_block + col;
-        const int k = kb * 4 * EPC + q * EPC + e;
-        float v = 0.f;
-        if (m < j.M && k < j.K) {
-            const int tt = j.flip ? (j.T - 1 - tap) : tap;
-            v = j.src[(long long)(m / j.M0) * j.s_m1 + (long long)(m % j.M0) * j.s_m0 + (long long)tt * j.s_t +
-                      (long long)(k / j.K0) * j.s_k1 + (long long)(k % j.K0) * j.s_k0];
+    // 32-bit index arithmetic (images are far below 2^31 elements); one thread packs one 16-byte chunk
+    const unsigned nchunks = (unsigned)(j.total / EPC), cb_w = (unsigned)j.cout_block, Tt = (unsigned)j.T, nkb = (unsigned)j.nkb;
+    for (unsigned ch = blockIdx.x * 256u + threadIdx.x; ch < nchunks; ch += gridDim.x * 256u) {
+        unsigned t = ch;
+        const unsigned col = t % cb_w; t /= cb_w;
+        const unsigned q = t & 3u; t >>= 2;
+        const unsigned tap = t % Tt; t /= Tt;
+        const unsigned kb = t % nkb;
+        const unsigned cb = t / nkb;
+        const int m = (int)(cb * cb_w + col);
+        const unsigned tt = j.flip ? (Tt - 1 - tap) : tap;
+        alignas(16) T out[EPC];
+        const bool mok = m < j.M;
+        const long long mbase = mok ? (long long)(m / j.M0) * j.s_m1 + (long long)(m % j.M0) * j.s_m0 + (long long)tt * j.s_t : 0;
+#pragma unroll
+        for (unsigned e = 0; e < EPC; ++e) {
+            const int k = (int)(kb * 4 * EPC + q * EPC + e);
+            float v = 0.f;
+            if (mok && k < j.K) v = j.src[mbase + (long long)(k / j.K0) * j.s_k1 + (long long)(k % j.K0) * j.s_k0];
+            DT<T>::st(&out[e], v);
         }
-        DT<T>::st(dst + i, v);
+        *(u32x4_t*)(dst + (size_t)ch * EPC) = *(const u32x4_t*)out;
     }
 }
 

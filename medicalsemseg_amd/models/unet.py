@@ -13,6 +13,8 @@ gradient is accumulated into the skip gradient, and parameter gradients land dir
 """
 from __future__ import annotations
 
+import os
+
 from typing import Sequence
 
 import torch
@@ -188,7 +190,7 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def _backward_body(ctx, net, saved, dl, f, n_in):
         side = layers.WGRAD_SIDE
-        side.set_mode(side.DEFER)
+        side.set_mode(side.DEFER if os.environ.get("MSSEG_WGRAD_STREAM") == "defer" else side.INLINE)
         g = net._final.bwd(ctx.last, dl, True, dy_channels=LOGIT_LD)
         skip_grads = [None] * 4
         for j in range(3, -1, -1):  # decoder levels 0..3 in reverse order of execution
