@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="single GPU: use the multi-GPU replay structure (graph A | eager gap | graph B)")
     ap.add_argument("--workload", default="unet", choices=["unet", "swin_unetr", "sliding_window"],
                     help="unet = the headline (BASELINE configs[1]); swin_unetr = configs[3]; sliding_window = configs[4]")
     ap.add_argument("--sw-size", type=int, default=512)
@@ -178,10 +180,36 @@ def main():
     for _ in range(max(args.warmup, 1)):
         loss = step()
     sync()
-    # Single-GPU: replay the whole step (forward + loss + backward + AdamW) from ONE captured hipGraph; the work per
-    # replay is exactly the eager step's.  Multi-GPU keeps eager launches (the RCCL all-reduce stays outside graphs).
+    # Replay the step from captured hipGraphs; the work per replay is exactly the eager step's.  Single GPU: ONE graph
+    # (forward + loss + backward + AdamW).  Multi-GPU (or --split-graph): graph A = forward + loss + backward, then
+    # the RCCL all-reduce of the flat gradient buffer as an ordinary eager call, then graph B = AdamW + zero_grad --
+    # the collective stays outside the graphs, the ~200 kernel launches of the step do not pay Python per launch.
     graph = None
-    if world == 1 and not args.no_graph:
+    graph_b = None
+    split = world > 1 or args.split_graph
+
+    def part_a():
+        out = net((x, None, None))
+        loss = crit(out, y)
+        loss.backward()
+        return loss
+
+    def part_mid():
+        if world > 1:
+            parallel.all_reduce_flat_grads(opt.flat_grad)
+            opt._gscale.mul_(1.0 / world)
+
+    def part_b():
+        opt.step()
+        opt.zero_grad()
+
+    def replay():
+        graph.replay()
+        if graph_b is not None:
+            part_mid()
+            graph_b.replay()
+
+    if not args.no_graph:
         try:
             from medicalsemseg_amd import layers
             side = torch.cuda.Stream()
@@ -191,18 +219,27 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             layers.bump_weights_epoch()   # capture must include the weight re-packing kernels
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = step()
-            graph.replay()
+            if not split:
+                with torch.cuda.graph(graph):
+                    static_loss = step()
+            else:
+                with torch.cuda.graph(graph):
+                    static_loss = part_a()
+                part_mid()
+                graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_b):
+                    part_b()
+                layers.bump_weights_epoch()
+            replay()
             sync()
         except Exception as e:  # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-            graph = None
+            graph = graph_b = None
             torch.cuda.synchronize()
     t0 = time.perf_counter()
     if graph is not None:
         for _ in range(args.steps):
-            graph.replay()
+            replay()
         loss = static_loss
     else:
         hip.TIMER.enabled = True
@@ -234,7 +271,8 @@ def main():
         "value": round(value, 3), "unit": "vol/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "launch": "hipGraph replay" if graph is not None else "eager",
+        "launch": ("hipGraph replay" if graph_b is None else "hipGraph replay (fwd+bwd | all-reduce | optimiser)")
+                  if graph is not None else "eager",
         "config": {"workload": f"UNet base (MONAI BasicUNet 32-32-64-128-256-32) 1->{args.classes}cls, {args.size}^3 "
                                f"patches, DiceCE + AdamW, per-GPU batch {args.batch}", "global_batch": args.batch * world,
                    "parallelism": f"dp{world}", "final_loss": round(loss_v, 5)},
