@@ -217,6 +217,7 @@ def main():
             with torch.cuda.stream(side):
                 step()
             torch.cuda.current_stream().wait_stream(side)
+            layers.PACK_REGISTRY.prepare()
             layers.bump_weights_epoch()   # capture must include the weight re-packing kernels
             graph = torch.cuda.CUDAGraph()
             if not split:

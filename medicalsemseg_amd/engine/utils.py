@@ -12,6 +12,8 @@ to the single-GPU result).
 """
 from __future__ import annotations
 
+import os
+
 import itertools
 import math
 from typing import Callable, List, Sequence, Tuple
@@ -98,6 +100,43 @@ def importance_map(patch_size: Sequence[int], mode="constant", sigma_scale=0.125
     return imp.to(device) if device is not None else imp
 
 
+class _GraphedPredictor:
+    """Replays `predictor((win, None, None))` on a static window batch from a captured hipGraph (models that declare
+    `graph_safe`: static shapes, no host synchronisation, no autograd).  A window batch is ~70 kernel launches of
+    20-100 us each: issued from Python they are launch-bound.  The captured graph starts with the batched weight
+    re-packing, so a replay always sees the current parameters."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, predictor, win: torch.Tensor):
+        key = (id(predictor), tuple(win.shape), win.dtype, win.device)
+        g = cls._cache.get(key)
+        if g is None or g.predictor() is not predictor:
+            g = cls._cache[key] = cls(predictor, win)
+        return g
+
+    def __init__(self, predictor, win: torch.Tensor):
+        import weakref
+        from .. import layers
+        self.predictor = weakref.ref(predictor)
+        self.win = torch.zeros_like(win)
+        side = torch.cuda.Stream(device=win.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            predictor((self.win, None, None))
+        torch.cuda.current_stream().wait_stream(side)
+        layers.PACK_REGISTRY.prepare()
+        layers.bump_weights_epoch()   # the capture then starts with the batched weight re-packing
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = predictor((self.win, None, None))
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out
+
+
 def sliding_window_inference(inputs: torch.Tensor, affine, roi_size, sw_batch_size: int, predictor: Callable,
                              overlap: float = 0.25, mode: str = "constant", sigma_scale=0.125,
                              padding_mode: str = "constant", cval: float = 0.0, sw_device=None, device=None,
@@ -129,18 +168,29 @@ def sliding_window_inference(inputs: torch.Tensor, affine, roi_size, sw_batch_si
     lo, hi = parallel.shard_windows(total, ws, rk)
     per_rank = -(-total // ws)
     my_logits = None
+    # graph replay of the window forward: models that ignore (centers, affine) and declare themselves graph-safe
+    graphed = None
+    if (getattr(predictor, "graph_safe", False) and not torch.is_grad_enabled() and not args and not kwargs
+            and not os.environ.get("MSSEG_NO_SW_GRAPH") and hi - lo >= sw_batch_size):
+        graphed = _GraphedPredictor.get(predictor, torch.empty(sw_batch_size, Cin, *roi, dtype=torch.float32, device=dev))
     for g in range(lo, hi, sw_batch_size):
         idxs = list(range(g, min(g + sw_batch_size, hi)))
-        win = torch.empty(len(idxs), Cin, *roi, dtype=torch.float32, device=dev)
+        if graphed is not None:
+            win = graphed.win   # a short last batch keeps the previous batch's windows in the unused slots
+        else:
+            win = torch.empty(len(idxs), Cin, *roi, dtype=torch.float32, device=dev)
         centers = []
         for j, idx in enumerate(idxs):
             b, st = idx // num_win, starts[idx % num_win]
             hip.sw_gather(vol[b], win[j], tuple(st[d] - pad_lo[d] for d in range(3)), cval)
             centers.append([(st[d] + roi[d] - roi[d] // 2) / image_size[d] for d in range(3)])
-        centers = torch.tensor(centers, dtype=torch.float32, device=dev)
-        if sw_batch_size == 1:
-            centers = centers.unsqueeze(0)  # reference quirk (engine/utils.py:131-132)
-        seg = predictor((win, centers, affine), *args, **kwargs)
+        if graphed is not None:
+            seg = graphed()[:len(idxs)]
+        else:
+            centers = torch.tensor(centers, dtype=torch.float32, device=dev)
+            if sw_batch_size == 1:
+                centers = centers.unsqueeze(0)  # reference quirk (engine/utils.py:131-132)
+            seg = predictor((win, centers, affine), *args, **kwargs)
         if my_logits is None:
             ncls = seg.shape[1]
             my_logits = torch.zeros(per_rank, ncls, *roi, dtype=torch.float32, device=dev)

@@ -50,9 +50,7 @@ class _PackRegistry:
             g["jobs"] = [r for r in g["jobs"] if r["alive"]]
             g["table"] = None
 
-    def refresh(self, device, dtype):
-        import ctypes
-        g = self.groups[(device, dtype)]
+    def _ensure_table(self, g, device):
         jobs = g["jobs"]
         if g["table"] is None:
             arr = (hip.PackJob * len(jobs))(*[r["job"] for r in jobs])
@@ -61,6 +59,17 @@ class _PackRegistry:
                 g["keep"].append(g["last"])   # a captured hipGraph may still reference the previous table
             g["table"] = g["last"] = host.to(device)
             g["max_total"] = max(int(r["job"].total) for r in jobs)
+
+    def prepare(self):
+        """build every missing job table now (host-to-device copies are not allowed while a stream is capturing)"""
+        for (device, _), g in self.groups.items():
+            if g["jobs"]:
+                self._ensure_table(g, device)
+
+    def refresh(self, device, dtype):
+        g = self.groups[(device, dtype)]
+        jobs = g["jobs"]
+        self._ensure_table(g, device)
         hip.pack_weights_batch(g["table"], len(jobs), g["max_total"], dtype)
         for r in jobs:
             r["state"] = (r["src"]._version, weights_epoch)

@@ -76,6 +76,8 @@ class UNet(nn.Module):
 
     compute_dtype: torch.bfloat16 (speed) or torch.float32 (exact-fp32 MFMA path used for parity)."""
 
+    graph_safe = True   # static shapes, no host synchronisation: engine.utils may replay the forward from a hipGraph
+
     def __init__(self, in_channels=1, out_channels=2, features: Sequence[int] = UNET_FEATURES["UNet"],
                  compute_dtype=torch.bfloat16, slope=0.1):
         super().__init__()
