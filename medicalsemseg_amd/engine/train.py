@@ -30,6 +30,58 @@ def _metric_update(metric_logger, criterion, outputs, labels, n_cls):
     return class_means.nanmean()
 
 
+class _GraphedFwdBwd:
+    """forward + loss + backward of one static-shape batch, replayed from a captured hipGraph.
+
+    A UNet step is ~200 kernel launches of 5-150 us; issued from Python they cost ~8 ms of host time per step against
+    ~5 ms of GPU time.  Models that declare `graph_safe` (static shapes, no host synchronisation inside the step) and
+    ignore (crop_loc, affine) take this path; the optimiser step, gradient clipping, the data-parallel all-reduce and
+    the metrics stay outside the graph, exactly where the reference loop has them."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, model, criterion, optimizer, inputs, labels):
+        key = (id(model), id(criterion), tuple(inputs.shape), inputs.dtype, tuple(labels.shape), labels.dtype, inputs.device)
+        g = cls._cache.get(key)
+        if g is None or g.model() is not model:
+            g = cls._cache[key] = cls(model, criterion, optimizer, inputs, labels)
+        return g
+
+    def __init__(self, model, criterion, optimizer, inputs, labels):
+        import weakref
+        from .. import layers
+        self.model = weakref.ref(model)
+        self.x, self.y = inputs.clone(), labels.clone()
+        side = torch.cuda.Stream(device=inputs.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):   # builds the packed-weight images, workspaces and gradient views
+            criterion(model((self.x, None, None)), self.y).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        optimizer.zero_grad()           # the warm-up pass must not count
+        layers.PACK_REGISTRY.prepare()
+        layers.bump_weights_epoch()     # the capture then starts with the batched weight re-packing
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = model((self.x, None, None))
+            self.loss = criterion(self.out, self.y)
+            self.loss.backward()
+
+    def __call__(self, inputs, labels):
+        self.x.copy_(inputs)
+        self.y.copy_(labels)
+        self.graph.replay()
+        return self.out, self.loss
+
+
+def _graph_ok(model, criterion, optimizer, loss_scaler, inputs, cfg):
+    import os
+    net = getattr(model, "module", model)
+    return (inputs.is_cuda and getattr(net, "graph_safe", False) and isinstance(criterion, L.DiceCELoss)
+            and hasattr(optimizer, "flat_grad") and not getattr(loss_scaler, "is_enabled", lambda: False)()
+            and not bool(getattr(cfg, "anomaly_detection", False)) and not os.environ.get("MSSEG_NO_TRAIN_GRAPH"))
+
+
 def train_one_epoch(model, data_loader, optimizer, criterion, device, epoch, loss_scaler, cfg, log_writer=None):
     model.train()
     metric_logger = misc.MetricLogger(delimiter="  ")
@@ -50,14 +102,19 @@ def train_one_epoch(model, data_loader, optimizer, criterion, device, epoch, los
             if t["class"][0] in ("RandCropByPosNegLabeld", "RandCropByClassesd"):
                 crop_loc = misc.get_rel_crop_loc(t)
 
-        outputs = model((inputs, crop_loc, aff_xyz))   # compute dtype is a property of the model (bf16 / fp32)
-        loss = criterion(outputs, labels)
+        graphed = _graph_ok(model, criterion, optimizer, loss_scaler, inputs, cfg)
+        if graphed:
+            outputs, loss = _GraphedFwdBwd.get(model, criterion, optimizer, inputs, labels)(inputs, labels)
+        else:
+            outputs = model((inputs, crop_loc, aff_xyz))   # compute dtype is a property of the model (bf16 / fp32)
+            loss = criterion(outputs, labels)
         loss_value = loss.item()
         if not math.isfinite(loss_value):
             print("Loss is {}, stopping training".format(loss_value))
             sys.exit(1)
 
-        loss_scaler.scale(loss).backward()
+        if not graphed:
+            loss_scaler.scale(loss).backward()
         if cfg.gradient_clipping is not None:
             loss_scaler.unscale_(optimizer)
             if hasattr(optimizer, "clip_grad_norm_"):

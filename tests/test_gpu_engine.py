@@ -66,6 +66,37 @@ def test_engine_loops_on_gpu():
     assert set(v) >= {"val/loss", "val/mDice"} and np.isfinite(v["val/loss"])
 
 
+def test_train_epoch_graph_replay_equals_eager(monkeypatch):
+    """the hipGraph replay of forward+loss+backward inside train_one_epoch is the eager step, launch for launch"""
+    from medicalsemseg_amd.data import SyntheticLoader
+    from medicalsemseg_amd.engine.train import train_one_epoch
+    from medicalsemseg_amd.losses import DiceCELoss
+    from medicalsemseg_amd.models.model_builder import build_model
+    from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay
+    from medicalsemseg_amd.utils.arguments import get_args
+    cfg = get_args("--model UNetSmall --output_dim 2 --vol_size 32 --gradient_clipping 1.0".split())
+
+    def run(eager):
+        if eager:
+            monkeypatch.setenv("MSSEG_NO_TRAIN_GRAPH", "1")
+        else:
+            monkeypatch.delenv("MSSEG_NO_TRAIN_GRAPH", raising=False)
+        torch.manual_seed(0)
+        model = build_model(cfg).to(DEV)
+        opt = FlatAdamW(add_weight_decay(model, 1e-5), lr=2e-3, betas=(0.9, 0.95), eps=1e-6)
+        scaler = torch.amp.GradScaler("cuda", enabled=False)
+        stats = [train_one_epoch(model, SyntheticLoader(4, 2, 32, 1, 2, seed=1), opt, DiceCELoss(), torch.device(DEV), e,
+                                 scaler, cfg)["train/loss"] for e in range(2)]
+        return stats, opt.flat_param.clone()
+
+    (la, pa), (lb, pb) = run(True), run(False)
+    # same kernels in the same order; the DiceCE partial sums use float atomics, so runs agree to rounding only
+    assert la == pytest.approx(lb, rel=2e-4)
+    # (Adam turns a rounding-level difference of a near-zero gradient into a full +-lr step: bound the mean tightly,
+    # the maximum by lr * steps)
+    assert float((pa - pb).abs().mean()) < 2e-5 and float((pa - pb).abs().max()) < 2e-3 * 8
+
+
 def test_run_training_driver_synthetic(tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, "run_training.py"), "--synthetic", "--model", "UNetSmall", "--output_dim", "2",
            "--vol_size", "32", "--n_images_per_batch", "2", "--synthetic_steps", "3", "--epochs", "2", "--val_interval", "2",
