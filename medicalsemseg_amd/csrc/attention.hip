@@ -297,6 +297,145 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
 }
 
+// Vector forms: LPR lanes (a power of two <= 64) share one token row, 16-byte chunks, the row stays in registers between
+// the statistics and the normalisation (one pass over HBM); reductions by xor-shuffles inside the lane group.
+struct LnVecParams {
+    const void* x; long long ldx; const float* g; const float* b; void* y; long long ldy;
+    float* mean; float* rstd; const void* dy; long long lddy; long long rows; int C, lpr, nch; float eps;
+};
+
+template <typename T> MSSEG_DEVFN void ln_load(const T* p, float (&v)[DT<T>::EPC]) {
+    const u32x4_t raw = *(const u32x4_t*)p;
+    if constexpr (sizeof(T) == 2) {
+        const bf16x8_t h = __builtin_bit_cast(bf16x8_t, raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    } else {
+        const f32x4_t f = __builtin_bit_cast(f32x4_t, raw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = f[e];
+    }
+}
+template <typename T> MSSEG_DEVFN void ln_store(T* p, const float (&v)[DT<T>::EPC]) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8_t h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (bf16_t)v[e];
+        *(u32x4_t*)p = __builtin_bit_cast(u32x4_t, h);
+    } else {
+        *(f32x4_t*)p = f32x4_t{v[0], v[1], v[2], v[3]};
+    }
+}
+
+template <typename T, int MAXCH, bool BWD>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const LnVecParams p) {
+    constexpr int EPC = DT<T>::EPC;
+    const int lane = threadIdx.x & 63, sub = lane & (p.lpr - 1), rows_per_wave = 64 / p.lpr;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    const float invC = 1.0f / (float)p.C;
+    // per-chunk affine parameters of this lane
+    float gv[MAXCH][EPC], bv[MAXCH][EPC];
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int ch = sub + k * p.lpr;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            gv[k][e] = (ch < p.nch && p.g) ? p.g[ch * EPC + e] : 1.f;
+            bv[k][e] = (!BWD && ch < p.nch && p.b) ? p.b[ch * EPC + e] : 0.f;
+        }
+    }
+    for (long long r0 = wave_id * rows_per_wave; r0 < p.rows; r0 += nwaves * rows_per_wave) {
+        const long long r = r0 + lane / p.lpr;
+        const bool rok = r < p.rows;
+        float xv[MAXCH][EPC], dv[MAXCH][EPC];
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int ch = sub + k * p.lpr;
+            const bool ok = rok && ch < p.nch;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) xv[k][e] = dv[k][e] = 0.f;
+            if (ok) {
+                ln_load<T>((const T*)p.x + r * p.ldx + ch * EPC, xv[k]);
+                if constexpr (BWD) ln_load<T>((const T*)p.dy + r * p.lddy + ch * EPC, dv[k]);
+            }
+        }
+        if constexpr (!BWD) {
+            float s = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXCH; ++k)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { s += xv[k][e]; s2 += xv[k][e] * xv[k][e]; }
+            for (int o = p.lpr >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o); }
+            const float mu = s * invC;
+            float var = s2 * invC - mu * mu;
+            var = var > 0.f ? var : 0.f;
+            const float rs = rsqrtf(var + p.eps);
+            if (rok && sub == 0 && p.mean) { p.mean[r] = mu; p.rstd[r] = rs; }
+#pragma unroll
+            for (int k = 0; k < MAXCH; ++k) {
+                const int ch = sub + k * p.lpr;
+                if (rok && ch < p.nch) {
+                    float o[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o[e] = (xv[k][e] - mu) * rs * gv[k][e] + bv[k][e];
+                    ln_store<T>((T*)p.y + r * p.ldy + ch * EPC, o);
+                }
+            }
+        } else {
+            const float mu = rok ? p.mean[r] : 0.f, rs = rok ? p.rstd[r] : 0.f;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXCH; ++k)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float dyg = dv[k][e] * gv[k][e];
+                    a += dyg;
+                    b += dyg * ((xv[k][e] - mu) * rs);
+                }
+            for (int o = p.lpr >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            a *= invC; b *= invC;
+#pragma unroll
+            for (int k = 0; k < MAXCH; ++k) {
+                const int ch = sub + k * p.lpr;
+                if (rok && ch < p.nch) {
+                    float o[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o[e] = rs * (dv[k][e] * gv[k][e] - a - (xv[k][e] - mu) * rs * b);
+                    ln_store<T>((T*)p.y + r * p.ldy + ch * EPC, o);
+                }
+            }
+        }
+    }
+}
+
+// returns false when the vector form does not apply (unaligned rows / odd channel counts)
+template <typename T, bool BWD> bool launch_ln_vec(LnVecParams p, hipStream_t stream) {
+    constexpr int EPC = DT<T>::EPC;
+    const size_t esz = sizeof(T);
+    if (p.C % EPC || ((uintptr_t)p.x & 15) || ((uintptr_t)p.y & 15) || (p.ldx * esz) % 16 || (p.ldy * esz) % 16) return false;
+    if (BWD && (((uintptr_t)p.dy & 15) || (p.lddy * esz) % 16)) return false;
+    p.nch = p.C / EPC;
+    int lpr = 1;
+    while (lpr < p.nch && lpr < 64) lpr <<= 1;
+    p.lpr = lpr;
+    const int maxch = (p.nch + lpr - 1) / lpr;
+    if (maxch > 4) return false;
+    const long long waves = (p.rows + (64 / lpr) - 1) / (64 / lpr);
+    long long blocks = (waves + 3) / 4;
+    const long long cap = (long long)msseg_num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks);
+    switch (maxch) {
+        case 1: hipLaunchKernelGGL((layernorm_vec_kernel<T, 1, BWD>), grid, dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((layernorm_vec_kernel<T, 2, BWD>), grid, dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((layernorm_vec_kernel<T, 3, BWD>), grid, dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL((layernorm_vec_kernel<T, 4, BWD>), grid, dim3(256), 0, stream, p); break;
+    }
+    return true;
+}
+
 template <typename T, bool BWD>
 __global__ void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, long long n) {
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -396,6 +535,14 @@ int msseg_window_attention_bwd(const void* qkv, const float* qkv_bias, const flo
 int msseg_layernorm_fwd(const void* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
                         float* mean, float* rstd, long long rows, int C, float eps, int dtype, msseg_stream_t stream) {
     if (!x || !y || rows < 1 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "layernorm_fwd: bad args");
+    if (dtype == MSSEG_F32 || dtype == MSSEG_BF16) {
+        LnVecParams v{};
+        v.x = x; v.ldx = ldx; v.g = gamma; v.b = beta; v.y = y; v.ldy = ldy; v.mean = mean; v.rstd = rstd;
+        v.rows = rows; v.C = C; v.eps = eps;
+        const bool done = dtype == MSSEG_F32 ? launch_ln_vec<float, false>(v, (hipStream_t)stream)
+                                             : launch_ln_vec<bf16_t, false>(v, (hipStream_t)stream);
+        if (done) { MSSEG_CHECK_LAUNCH("layernorm_fwd"); return MSSEG_OK; }
+    }
     const int g = grid_for(rows, 1);
     if (dtype == MSSEG_F32)
         hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx,
@@ -412,6 +559,14 @@ int msseg_layernorm_bwd(const void* x, long long ldx, const float* gamma, const 
                         const void* dy, long long lddy, void* dx, long long lddx, long long rows, int C, int dtype,
                         msseg_stream_t stream) {
     if (!x || !mean || !rstd || !dy || !dx || rows < 1 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "layernorm_bwd: bad args");
+    if (dtype == MSSEG_F32 || dtype == MSSEG_BF16) {
+        LnVecParams v{};
+        v.x = x; v.ldx = ldx; v.g = gamma; v.y = dx; v.ldy = lddx; v.mean = (float*)mean; v.rstd = (float*)rstd;
+        v.dy = dy; v.lddy = lddy; v.rows = rows; v.C = C;
+        const bool done = dtype == MSSEG_F32 ? launch_ln_vec<float, true>(v, (hipStream_t)stream)
+                                             : launch_ln_vec<bf16_t, true>(v, (hipStream_t)stream);
+        if (done) { MSSEG_CHECK_LAUNCH("layernorm_bwd"); return MSSEG_OK; }
+    }
     float* dgamma = nullptr;
     float* dbeta = nullptr;
     const int g = grid_for(rows, 1);

@@ -741,7 +741,28 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         bc1 = 1.f - powf(b1, st);
         bc2_sqrt = sqrtf(1.f - powf(b2, st));
     }
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    // four parameters per thread (16-byte accesses) when the buffers allow it; scalar tail / unaligned fallback
+    const bool vec = (n % 4 == 0) && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) &&
+                     (!decay || (((uintptr_t)decay & 3) == 0));
+    const long long nv = vec ? n / 4 : 0;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        f32x4_t pi = ((const f32x4_t*)p)[i], mi = ((const f32x4_t*)m)[i], vi = ((const f32x4_t*)v)[i];
+        const f32x4_t gi = ((const f32x4_t*)g)[i];
+        const uint32_t dm = decay ? ((const uint32_t*)decay)[i] : 0x01010101u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gi[e] * gs;
+            float pe = pi[e];
+            if ((dm >> (8 * e)) & 0xffu) pe *= (1.f - lr * wd);
+            const float me = b1 * mi[e] + (1.f - b1) * ge;
+            const float ve = b2 * vi[e] + (1.f - b2) * ge * ge;
+            mi[e] = me; vi[e] = ve;
+            const float denom = sqrtf(ve) / bc2_sqrt + eps;
+            pi[e] = pe - (lr / bc1) * (me / denom);
+        }
+        ((f32x4_t*)m)[i] = mi; ((f32x4_t*)v)[i] = vi; ((f32x4_t*)p)[i] = pi;
+    }
+    for (long long i = nv * 4 + blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float gi = g[i] * gs;
         float pi = p[i];
         if (!decay || decay[i]) pi *= (1.f - lr * wd);

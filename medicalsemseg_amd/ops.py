@@ -8,7 +8,16 @@ from __future__ import annotations
 
 import torch
 
-from . import hip
+from . import hip, layers
+
+def _packed(weight, dtype, kind, builder):
+    """packed-weight images live on the parameter object: built once, refreshed by the batched repack of
+    layers.PACK_REGISTRY after each optimiser step (instead of one pack launch per forward / backward call)"""
+    c = getattr(weight, "_msseg_packed", None)
+    if c is None:
+        c = layers.PackedCache()
+        weight._msseg_packed = c
+    return c.get(weight, dtype, kind, builder)
 
 
 def _c(x):
@@ -23,7 +32,7 @@ class LinearFn(torch.autograd.Function):
         x = _c(x)
         cout, cin = weight.shape
         T = x.dtype
-        wp = hip.pack_conv_k1(weight.detach().contiguous(), T)
+        wp = _packed(weight, T, "f", lambda: hip.pack_conv_k1(weight.detach().contiguous(), T))
         y = torch.empty(x.shape[:-1] + (cout,), dtype=T, device=x.device)
         hip.conv3d_k1(x, wp, bias, y, cin, cout)
         ctx.save_for_backward(x, weight)
@@ -38,7 +47,7 @@ class LinearFn(torch.autograd.Function):
         T = x.dtype
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wpd = hip.pack_conv_k1(weight.detach().contiguous(), T, dgrad=True)
+            wpd = _packed(weight, T, "d", lambda: hip.pack_conv_k1(weight.detach().contiguous(), T, dgrad=True))
             dx = torch.empty_like(x)
             hip.conv3d_k1(dy, wpd, None, dx, cout, cin)
         if ctx.needs_input_grad[1]:
@@ -130,11 +139,12 @@ class Conv3Fn(torch.autograd.Function):
         T = x.dtype
         B, D, H, W, _ = x.shape
         if stride == 1:
-            wp = hip.pack_conv_k3(weight.detach().contiguous(), T, vol=(B, D, H, W))
+            vol = (B, D, H, W)
+            wp = _packed(weight, T, ("f", vol), lambda: hip.pack_conv_k3(weight.detach().contiguous(), T, vol=vol))
             y = torch.empty(B, D, H, W, cout, dtype=T, device=x.device)
             hip.conv3d_k3(x, wp, bias, y, cin, cout)
         else:
-            wp = hip.pack_conv_k3(weight.detach().contiguous(), T)
+            wp = _packed(weight, T, "f2", lambda: hip.pack_conv_k3(weight.detach().contiguous(), T))
             y = torch.empty(B, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1, cout, dtype=T, device=x.device)
             hip.conv3d_k3s2(x, wp, bias, y, cin, cout)
         ctx.save_for_backward(x, weight)
@@ -157,7 +167,9 @@ class Conv3Fn(torch.autograd.Function):
             dy = dyz
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wpd = hip.pack_conv_k3(weight.detach().contiguous(), T, dgrad=True, vol=tuple(dy.shape[:4]))
+            dvol = tuple(dy.shape[:4])
+            wpd = _packed(weight, T, ("d", dvol),
+                          lambda: hip.pack_conv_k3(weight.detach().contiguous(), T, dgrad=True, vol=dvol))
             dx = torch.empty_like(x)
             hip.conv3d_k3(dy, wpd, None, dx, cout, cin)
         if ctx.needs_input_grad[1]:
@@ -175,7 +187,7 @@ class PatchConvFn(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         T = x.dtype
         B, D, H, W, _ = x.shape
-        wp = hip.pack_conv_gather(weight.detach().contiguous(), T)
+        wp = _packed(weight, T, "g", lambda: hip.pack_conv_gather(weight.detach().contiguous(), T))
         y = torch.empty(B, D // k, H // k, W // k, cout, dtype=T, device=x.device)
         hip.conv3d_gather(x, wp, bias, y, cin, cout, k, k, 0)
         ctx.save_for_backward(x, weight)
