@@ -521,6 +521,11 @@ int msseg_window_attention_bwd(const void* qkv, const float* qkv_bias, const flo
     if (int rc = fill_attn(p, B, S, H, W, C, heads, ws, shift)) return rc;
     p.qkv = qkv; p.qkv_bias = qkv_bias; p.table = table; p.out = (void*)out; p.lse = (float*)lse; p.dout = dout;
     p.dqkv = dqkv; p.dtable = dtable;
+    if (dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 224 && (C % 8) == 0 && !getenv("MSSEG_ATTN_NO_MFMA") &&
+        !getenv("MSSEG_ATTN_BWD_NO_MFMA")) {
+        // bf16: all five contractions of the backward on the matrix cores (attention_mfma.hip)
+        return msseg_window_attention_bwd_mfma(p, (hipStream_t)stream);
+    }
     const size_t base = (size_t)p.N * p.hd * 4 * 4 + (size_t)p.N * 5 * 4 + (size_t)p.M3 * 4;
     p.dtab_all_heads = (base + (size_t)heads * p.M3 * 4 <= 96 * 1024) ? 1 : 0;
     const size_t smem = base + (size_t)(p.dtab_all_heads ? heads : 1) * p.M3 * 4;

@@ -42,3 +42,4 @@ MSSEG_DEVFN int window_token(const AttnParams& p, int wz, int wy, int wx, int po
 }  // namespace msseg_attn
 
 int msseg_window_attention_fwd_mfma(const msseg_attn::AttnParams& p, hipStream_t stream);  // attention_mfma.hip
+int msseg_window_attention_bwd_mfma(const msseg_attn::AttnParams& p, hipStream_t stream);

@@ -164,6 +164,282 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const AttnParams
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// backward (bf16): dQ, dK, dV and the relative-position-bias gradient.
+//
+// Two passes per (window, head), both on v_mfma_f32_32x32x16_bf16 with the same "accumulator = next B operand" trick
+// as the forward:
+//   pass 1, a wave per 32-query tile i, keys j streamed:  S^T = K_j Q_i^T and dP^T = V_j dO_i^T have the query on the lane
+//           (lse_i, delta_i are per-lane scalars), dS^T = P^T (dP^T - delta_i) in registers IS the B operand of
+//           dQ_i^T += K_j^T dS^T; dtable[code_q - code_k] += dS goes to LDS bins with float atomics (as the vector kernel).
+//   pass 2, a wave per 32-key tile j, queries i streamed:  S = Q_i K_j^T and dP = dO_i V_j^T have the key on the lane and
+//           the queries in the registers; P and dS feed dV_j^T += dO_i^T P and dK_j^T += Q_i^T dS.
+// Scores are recomputed in each pass (2 + 2 MFMAs per tile pair at head dim 16) instead of transposing a 32 x 32
+// accumulator through LDS.  Semantics (padded tokens carry the qkv bias, padded queries get no gradient, padded rows
+// of the MFMA tiles are masked) follow win_attn_bwd_kernel in attention.hip.
+template <int HD, int NKT>
+__global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams p) {
+    constexpr int NP = NKT * 32;
+    constexpr int KS = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* qS = (bf16_t*)smem;                    // row-major [NP][HD]
+    bf16_t* kS = qS + NP * HD;
+    bf16_t* vS = kS + NP * HD;
+    bf16_t* oS = vS + NP * HD;                     // dO
+    bf16_t* qT = oS + NP * HD;                     // transposed [HD][NP]
+    bf16_t* kT = qT + HD * NP;
+    bf16_t* oT = kT + HD * NP;
+    float* lseS = (float*)(oT + HD * NP);          // [NP]
+    float* delS = lseS + NP;                       // [NP]
+    float* tabS = delS + NP;                       // [M3]
+    float* dtabS = tabS + p.M3;                    // [M3]
+    int* tok = (int*)(dtabS + p.M3);               // [NP]
+    unsigned short* kinfo = (unsigned short*)(tok + NP);  // [NP] code | region << 11 ; 0xFFFF = padded row of the tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int nW = p.nWs * p.nWh * p.nWw;
+    const int m = 2 * p.ws - 1;
+    const int off = ((p.ws - 1) * m + (p.ws - 1)) * m + (p.ws - 1);
+    const int C3 = 3 * p.C;
+    const int vrow = r & (HD - 1);
+
+    for (int wb = blockIdx.x; wb < p.nwin_total; wb += gridDim.x) {
+        const int w = wb % nW, b = wb / nW;
+        const int wx = w % p.nWw, wy = (w / p.nWw) % p.nWh, wz = w / (p.nWw * p.nWh);
+        const long long vol = (long long)p.S * p.H * p.W;
+        const bf16_t* qkv = (const bf16_t*)p.qkv + b * vol * C3;
+        const bf16_t* outp = (const bf16_t*)p.out + b * vol * p.C;
+        const bf16_t* dout = (const bf16_t*)p.dout + b * vol * p.C;
+        bf16_t* dqkv = (bf16_t*)p.dqkv + b * vol * C3;
+        __syncthreads();
+        for (int i = tid; i < NP; i += 256) {
+            if (i < p.N) {
+                int rg, cd;
+                tok[i] = window_token(p, wz, wy, wx, i, rg, cd);
+                kinfo[i] = (unsigned short)(cd | (rg << 11));
+            } else {
+                tok[i] = -2;
+                kinfo[i] = 0xFFFF;
+            }
+        }
+        for (int h = 0; h < p.heads; ++h) {
+            __syncthreads();
+            for (int i = tid; i < p.M3; i += 256) { tabS[i] = p.table[(long long)i * p.heads + h]; dtabS[i] = 0.f; }
+            constexpr int CPT = HD / 8;
+            for (int i = tid; i < NP * CPT * 4; i += 256) {   // q, k, v, dO
+                const int which = i / (NP * CPT), rem = i % (NP * CPT);
+                const int t = rem / CPT, ch = rem % CPT;
+                const int tk = tok[t];
+                bf16x8_t v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+                if (tk >= 0) {
+                    v = (which < 3) ? *(const bf16x8_t*)(qkv + (long long)tk * C3 + which * p.C + h * HD + ch * 8)
+                                    : *(const bf16x8_t*)(dout + (long long)tk * p.C + h * HD + ch * 8);
+                } else if (tk == -1 && p.qkv_bias && which < 3) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)p.qkv_bias[which * p.C + h * HD + ch * 8 + e];
+                }
+                bf16_t* rowm = which == 0 ? qS : (which == 1 ? kS : (which == 2 ? vS : oS));
+                *(bf16x8_t*)(rowm + t * HD + ch * 8) = v;
+                bf16_t* colm = which == 0 ? qT : (which == 1 ? kT : (which == 3 ? oT : nullptr));
+                if (colm != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) colm[(ch * 8 + e) * NP + t] = v[e];
+                }
+            }
+            for (int i = tid; i < NP; i += 256) {
+                float d = 0.f, ls = 0.f;
+                if (i < p.N) {
+                    ls = p.lse[((long long)wb * p.heads + h) * p.N + i];
+                    const int t = tok[i];
+                    if (t >= 0) {
+#pragma unroll
+                        for (int c8 = 0; c8 < HD / 8; ++c8) {
+                            const bf16x8_t a = *(const bf16x8_t*)(dout + (long long)t * p.C + h * HD + c8 * 8);
+                            const bf16x8_t o = *(const bf16x8_t*)(outp + (long long)t * p.C + h * HD + c8 * 8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) d += (float)a[e] * (float)o[e];
+                        }
+                    }
+                }
+                lseS[i] = ls;
+                delS[i] = d;
+            }
+            __syncthreads();
+            // ------------------------------ pass 1: dQ (+ dtable) ------------------------------
+            for (int qt = wave; qt < NKT; qt += 4) {
+                const int qi = qt * 32 + r;
+                const unsigned short qinfo = kinfo[qi];
+                const bool qlive = tok[qi] >= 0;
+                const int qcode = (qinfo == 0xFFFF ? 0 : (qinfo & 2047)) + off, qreg = qinfo >> 11;
+                const float lq = lseS[qi], dq_del = delS[qi];
+                bf16x8_t qf[KS], of[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    qf[s] = *(const bf16x8_t*)(qS + qi * HD + s * 16 + hh * 8);
+                    of[s] = *(const bf16x8_t*)(oS + qi * HD + s * 16 + hh * 8);
+                }
+                f32x16_t Y;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) Y[g] = 0.f;
+#pragma unroll 1
+                for (int j = 0; j < NKT; ++j) {
+                    f32x16_t X, DP;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) X[g] = DP[g] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const bf16x8_t kf = *(const bf16x8_t*)(kS + (j * 32 + r) * HD + s * 16 + hh * 8);
+                        const bf16x8_t vf = *(const bf16x8_t*)(vS + (j * 32 + r) * HD + s * 16 + hh * 8);
+                        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], X, 0, 0, 0);
+                        DP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, of[s], DP, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const int key = j * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                        const unsigned short ki = kinfo[key];
+                        float ds = 0.f;
+                        if (ki != 0xFFFF && qinfo != 0xFFFF) {
+                            const int ti = qcode - (ki & 2047);
+                            float sc = X[g] * p.scale + tabS[ti];
+                            if (p.use_mask && (ki >> 11) != qreg) sc += -100.f;
+                            const float pr = __expf(sc - lq);
+                            ds = pr * (DP[g] - dq_del);
+                            if (p.dtable && qlive) atomicAdd(&dtabS[ti], ds);
+                        }
+                        X[g] = ds;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        bf16x8_t df;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) df[e] = (bf16_t)X[8 * s + e];
+                        const bf16_t* kp = kT + vrow * NP + j * 32 + 16 * s + 4 * hh;
+                        const bf16x4_t k0 = *(const bf16x4_t*)kp;
+                        const bf16x4_t k1 = *(const bf16x4_t*)(kp + 8);
+                        const bf16x8_t kf = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+                        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, df, Y, 0, 0, 0);
+                    }
+                }
+                const int tk = tok[qi];
+                if (qi < p.N && tk >= 0) {
+                    bf16_t* drow = dqkv + (long long)tk * C3 + h * HD;
+#pragma unroll
+                    for (int g4 = 0; g4 < HD / 8; ++g4) {
+                        const bf16x4_t o = {(bf16_t)(Y[4 * g4 + 0] * p.scale), (bf16_t)(Y[4 * g4 + 1] * p.scale),
+                                            (bf16_t)(Y[4 * g4 + 2] * p.scale), (bf16_t)(Y[4 * g4 + 3] * p.scale)};
+                        *(bf16x4_t*)(drow + 8 * g4 + 4 * hh) = o;
+                    }
+                }
+            }
+            // ------------------------------ pass 2: dK, dV ------------------------------
+            for (int jt = wave; jt < NKT; jt += 4) {
+                const int kj = jt * 32 + r;
+                const unsigned short kinf = kinfo[kj];
+                const int kcode = (kinf == 0xFFFF) ? 0 : (kinf & 2047), kreg = kinf >> 11;
+                bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    kf[s] = *(const bf16x8_t*)(kS + kj * HD + s * 16 + hh * 8);
+                    vf[s] = *(const bf16x8_t*)(vS + kj * HD + s * 16 + hh * 8);
+                }
+                f32x16_t YK, YV;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) YK[g] = YV[g] = 0.f;
+#pragma unroll 1
+                for (int i = 0; i < NKT; ++i) {
+                    f32x16_t X, DP;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) X[g] = DP[g] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const bf16x8_t qf = *(const bf16x8_t*)(qS + (i * 32 + r) * HD + s * 16 + hh * 8);
+                        const bf16x8_t of = *(const bf16x8_t*)(oS + (i * 32 + r) * HD + s * 16 + hh * 8);
+                        X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[s], X, 0, 0, 0);
+                        DP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[s], DP, 0, 0, 0);
+                    }
+                    f32x16_t PR;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const int qrow = i * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                        const unsigned short qi2 = kinfo[qrow];
+                        float pr = 0.f, ds = 0.f;
+                        if (qi2 != 0xFFFF && kinf != 0xFFFF && tok[qrow] >= 0) {   // padded queries get no gradient
+                            float sc = X[g] * p.scale + tabS[(qi2 & 2047) + off - kcode];
+                            if (p.use_mask && (qi2 >> 11) != kreg) sc += -100.f;
+                            pr = __expf(sc - lseS[qrow]);
+                            ds = pr * (DP[g] - delS[qrow]);
+                        }
+                        PR[g] = pr;
+                        X[g] = ds;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        bf16x8_t df, pf;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { df[e] = (bf16_t)X[8 * s + e]; pf[e] = (bf16_t)PR[8 * s + e]; }
+                        const bf16_t* qp = qT + vrow * NP + i * 32 + 16 * s + 4 * hh;
+                        const bf16_t* op = oT + vrow * NP + i * 32 + 16 * s + 4 * hh;
+                        const bf16x4_t q0 = *(const bf16x4_t*)qp, q1 = *(const bf16x4_t*)(qp + 8);
+                        const bf16x4_t o0 = *(const bf16x4_t*)op, o1 = *(const bf16x4_t*)(op + 8);
+                        const bf16x8_t qf2 = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+                        const bf16x8_t of2 = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+                        YK = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf2, df, YK, 0, 0, 0);
+                        YV = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of2, pf, YV, 0, 0, 0);
+                    }
+                }
+                const int tk = tok[kj];
+                if (kj < p.N && tk >= 0) {
+                    bf16_t* drow = dqkv + (long long)tk * C3 + h * HD;
+#pragma unroll
+                    for (int g4 = 0; g4 < HD / 8; ++g4) {
+                        const bf16x4_t dk = {(bf16_t)(YK[4 * g4 + 0] * p.scale), (bf16_t)(YK[4 * g4 + 1] * p.scale),
+                                             (bf16_t)(YK[4 * g4 + 2] * p.scale), (bf16_t)(YK[4 * g4 + 3] * p.scale)};
+                        const bf16x4_t dv = {(bf16_t)YV[4 * g4 + 0], (bf16_t)YV[4 * g4 + 1], (bf16_t)YV[4 * g4 + 2],
+                                             (bf16_t)YV[4 * g4 + 3]};
+                        *(bf16x4_t*)(drow + p.C + 8 * g4 + 4 * hh) = dk;
+                        *(bf16x4_t*)(drow + 2 * p.C + 8 * g4 + 4 * hh) = dv;
+                    }
+                }
+            }
+            if (p.dtable) {
+                __syncthreads();
+                for (int i = tid; i < p.M3; i += 256) {
+                    const float v = dtabS[i];
+                    if (v != 0.f) atomicAdd(&p.dtable[(long long)i * p.heads + h], v);
+                }
+            }
+        }
+    }
+}
+
+template <int HD, int NKT> int launch_bwd(const AttnParams& p, hipStream_t stream) {
+    constexpr int NP = NKT * 32;
+    const size_t smem = (size_t)7 * NP * HD * 2 + (size_t)2 * NP * 4 + (size_t)2 * p.M3 * 4 + (size_t)NP * 4 + (size_t)NP * 2 + 16;
+    auto kern = win_attn_bwd_mfma_kernel<HD, NKT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            MSSEG_FAIL(MSSEG_ELAUNCH, "window_attention_bwd_mfma: cannot set dynamic LDS size");
+        attr_set = true;
+    }
+    if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd_mfma: window too large for LDS (%zu bytes)", smem);
+    int gx = p.nwin_total < msseg_num_cus() * 2 ? p.nwin_total : msseg_num_cus() * 2;
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), smem, stream, p);
+    MSSEG_CHECK_LAUNCH("window_attention_bwd_mfma");
+    return MSSEG_OK;
+}
+
+template <int HD> int launch_bwd_hd(const AttnParams& p, hipStream_t stream) {
+    const int nkt = (p.N + 31) / 32;
+    if (nkt == 1) return launch_bwd<HD, 1>(p, stream);
+    if (nkt == 2) return launch_bwd<HD, 2>(p, stream);
+    if (nkt <= 4) return launch_bwd<HD, 4>(p, stream);
+    return launch_bwd<HD, 7>(p, stream);
+}
+
 template <int HD, int NKT> int launch(const AttnParams& p, hipStream_t stream) {
     constexpr int NP = NKT * 32;
     const size_t smem = (size_t)3 * NP * HD * 2 + (size_t)p.M3 * 4 + (size_t)NP * 4 + (size_t)NP * 2 + 16;
@@ -182,6 +458,11 @@ template <int HD> int launch_hd(const AttnParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+int msseg_window_attention_bwd_mfma(const AttnParams& p, hipStream_t stream) {
+    if (p.M3 > 2047 || p.N > 224) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd_mfma: window too large");
+    return p.hd == 16 ? launch_bwd_hd<16>(p, stream) : launch_bwd_hd<32>(p, stream);
+}
 
 int msseg_window_attention_fwd_mfma(const AttnParams& p, hipStream_t stream) {
     if (p.M3 > 2047 || p.N > 224) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd_mfma: window too large");
