@@ -131,6 +131,16 @@ MSSEG_DEVFN void finalize_channels(const float* ws, int N, int nblk, int C, int 
     }
 }
 
+// Second step of every channel reduction: ONE 256-thread block adds the per-block partial rows (fixed order).  A
+// separate launch -- the kernel boundary makes the rows visible, where an in-kernel "last block finalises" pays an
+// agent-scope release (L2 write-back) per block plus an acquire: ~10-15 us per reduction on these sizes.
+struct FinalizeArgs {
+    const float* ws; int N, nblk, C, nper, mode; float* out; float* dp0; float* dp1; int accumulate;
+};
+__global__ __launch_bounds__(256) void channels_finalize_kernel(const FinalizeArgs a) {
+    finalize_channels(a.ws, a.N, a.nblk, a.C, a.nper, a.mode, a.out, a.dp0, a.dp1, a.accumulate);
+}
+
 // Reduction kernels run 512-thread blocks (8 waves per CU, one block per CU, 12+ loads in flight per thread): enough loads in flight to stream HBM
 // while the number of partial rows the finalising block has to add stays at one per CU.
 constexpr int RED_THREADS = 512;
@@ -212,8 +222,6 @@ __global__ __launch_bounds__(RED_THREADS) void channel_stats_kernel(const T* __r
             }
         }
     }
-    if (grid_last_block(counter, gridDim.x * gridDim.y, &lflag))
-        finalize_channels(ws, gridDim.y, gridDim.x, C, nacc, nacc == 2 ? 0 : 1, out, nullptr, nullptr, accumulate);
 }
 
 // LayerNorm parameter gradients: dgamma[c] = sum_rows dy*xhat, dbeta[c] = sum_rows dy  (xhat from per-row mean/rstd)
@@ -275,8 +283,6 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const T* __restrict_
             }
         }
     }
-    if (grid_last_block(counter, gridDim.x, &lflag))
-        finalize_channels(ws, 1, gridDim.x, C, 2, 2, ws + (long long)gridDim.x * C * 2, dgamma, dbeta, accumulate);
 }
 
 inline long long reduce_blocks(long long S, int rows_par, int N, int C, int nper);
@@ -298,6 +304,11 @@ int launch_ln_param_grad(const void* x, long long ldx, const void* dy, long long
         hipLaunchKernelGGL((ln_param_grad_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, ldx,
                            (const T*)dy, lddy, mean, rstd, rows, C, m.groups, m.rows_par, rpb, ws, counter, dgamma, dbeta, accumulate);
     MSSEG_CHECK_LAUNCH("ln_param_grad");
+    {
+        FinalizeArgs a{ws, 1, (int)blocks, C, 2, 2, ws + blocks * C * 2, dgamma, dbeta, accumulate};
+        hipLaunchKernelGGL(channels_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+        MSSEG_CHECK_LAUNCH("channels_finalize");
+    }
     return MSSEG_OK;
 }
 
@@ -331,6 +342,11 @@ int launch_stats(const void* x, long long ldx, float* out, int N, long long S, i
         hipLaunchKernelGGL((channel_stats_kernel<T, false>), grid, dim3(RED_THREADS), 0, st, (const T*)x, ldx, out, S, C,
                            m.groups, m.rows_par, rpb, nacc, accumulate, ws, counter);
     MSSEG_CHECK_LAUNCH("channel_stats");
+    {
+        FinalizeArgs a{ws, N, (int)blocks, C, nacc, nacc == 2 ? 0 : 1, out, nullptr, nullptr, accumulate};
+        hipLaunchKernelGGL(channels_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+        MSSEG_CHECK_LAUNCH("channels_finalize");
+    }
     return MSSEG_OK;
 }
 
@@ -508,11 +524,6 @@ __global__ __launch_bounds__(MODE == 1 ? RED_THREADS : 256) void instnorm_kernel
             }
         }
     }
-    if constexpr (MODE == 1) {
-        // red[n][c] = (sum dz, sum dz*xhat); dbeta = sum_n red0, dgamma = sum_n red1
-        if (grid_last_block(p.counter, gridDim.x * gridDim.y, &lflag))
-            finalize_channels(p.ws, gridDim.y, gridDim.x, p.C, 2, 2, p.red, p.dbeta, p.dgamma, p.accumulate);
-    }
 }
 
 template <typename T, int MODE> int launch_norm(NormParams& p, int N, bool vec, hipStream_t st) {
@@ -535,6 +546,12 @@ template <typename T, int MODE> int launch_norm(NormParams& p, int N, bool vec, 
     if (vec) hipLaunchKernelGGL((instnorm_kernel<T, true, MODE>), grid, dim3(NTHR), 0, st, p);
     else hipLaunchKernelGGL((instnorm_kernel<T, false, MODE>), grid, dim3(NTHR), 0, st, p);
     MSSEG_CHECK_LAUNCH("instnorm");
+    if (MODE == 1) {
+        // red[n][c] = (sum dz, sum dz*xhat); dbeta = sum_n red0, dgamma = sum_n red1
+        FinalizeArgs a{p.ws, N, (int)blocks, p.C, 2, 2, p.red, p.dbeta, p.dgamma, p.accumulate};
+        hipLaunchKernelGGL(channels_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+        MSSEG_CHECK_LAUNCH("channels_finalize");
+    }
     return MSSEG_OK;
 }
 

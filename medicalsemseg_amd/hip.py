@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsseg_hip.so")
+LIB_PATH = os.environ.get("MSSEG_LIB") or os.path.join(_HERE, "libmsseg_hip.so")   # MSSEG_LIB: A/B another build
 
 F32, BF16 = 0, 1
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
