@@ -724,13 +724,17 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const msseg_pac
     T* dst = (T*)j.dst;
     // 32-bit index arithmetic (images are far below 2^31 elements); one thread packs one 16-byte chunk
     const unsigned nchunks = (unsigned)(j.total / EPC), cb_w = (unsigned)j.cout_block, Tt = (unsigned)j.T, nkb = (unsigned)j.nkb;
-    for (unsigned ch = blockIdx.x * 256u + threadIdx.x; ch < nchunks; ch += gridDim.x * 256u) {
-        unsigned t = ch;
+    // work order: tap fastest, so that neighbouring threads read neighbouring source elements of a conv weight
+    // ([m][k][tap] in torch layout: the 8 k x T taps of a chunk group are one contiguous run); the destination chunk
+    // index is recomputed from the coordinates
+    for (unsigned wi = blockIdx.x * 256u + threadIdx.x; wi < nchunks; wi += gridDim.x * 256u) {
+        unsigned t = wi;
+        const unsigned tap = t % Tt; t /= Tt;
         const unsigned col = t % cb_w; t /= cb_w;
         const unsigned q = t & 3u; t >>= 2;
-        const unsigned tap = t % Tt; t /= Tt;
         const unsigned kb = t % nkb;
         const unsigned cb = t / nkb;
+        const unsigned ch = (((cb * nkb + kb) * Tt + tap) * 4u + q) * cb_w + col;
         const int m = (int)(cb * cb_w + col);
         const unsigned tt = j.flip ? (Tt - 1 - tap) : tap;
         alignas(16) T out[EPC];
