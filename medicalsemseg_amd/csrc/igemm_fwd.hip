@@ -746,7 +746,13 @@ static void k3_plan(int N, int D, int H, int W, int M, int* cfg, int* cb) {
     auto wgs = [&](int td, int th, int tw, int c) {
         return (long long)N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw) * ceil_div(M, c);
     };
-    if (mn >= 32 && wgs(4, 8, 16, std_cb) >= want) { *cfg = 0; *cb = std_cb; return; }
+    if (mn >= 32 && wgs(4, 8, 16, std_cb) >= want) {
+        *cfg = 0;
+        // the 48-wide (NT = 3) instantiation of the big tile spills (142 VGPRs): two 32-wide blocks, the second half
+        // empty, measured faster at 96^3 (48->48: 488 vs 633 us, 96->48: 731 vs 948 us; 16-wide blocks: 491 / 778 us)
+        *cb = (std_cb == 48) ? 32 : std_cb;
+        return;
+    }
     if (mn >= 12 && wgs(4, 4, 8, std_cb) >= want) { *cfg = 1; *cb = std_cb; return; }
     *cfg = 2;
     *cb = (wgs(2, 4, 8, std_cb) >= want || std_cb == 16) ? std_cb : 16;
