@@ -302,7 +302,8 @@ def main():
                 pass
             res["roofline"] = {"bound": "mfma", "kernel": name,
                                "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                               "traffic": traffic, "launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
+                               "traffic": traffic, "traffic_shape": "32->32 @96^3 B=2 launch (97.8 GFLOP, 226.5 MB algorithmic)" if traffic else None,
+                               "launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
                                "flops_per_launch_avg": round(k["flops"] / k["launches"]),
                                "share_of_step": round((k["total_ms"] / instr_steps) / (dt * 1e3 / args.steps), 3),
                                "all_k3_variants_tflops": round(sum(v["flops"] for v in allk) / (sum(v["total_ms"] for v in allk) * 1e-3) / 1e12, 2)}
