@@ -412,6 +412,36 @@ def test_conv3d_k3_fused_stats(dtype, cin, cout, sp, N):
     assert torch.equal(s2, stats)
 
 
+def test_batched_weight_packing_equals_single_packing():
+    """msseg_pack_weights_batch (one launch per network and step, layers.PACK_REGISTRY) == per-image msseg_pack_weights"""
+    from medicalsemseg_amd import hip, layers
+    dev = _dev()
+    ws = [torch.nn.Parameter(gen(*shape, seed=i).to(dev)) for i, shape in
+          enumerate([(32, 32, 3, 3, 3), (64, 32, 3, 3, 3), (48, 96, 3, 3, 3), (3, 32, 1, 1, 1), (32, 1, 3, 3, 3)])]
+    for dtype in DTYPES:
+        caches = [layers.PackedCache() for _ in ws]
+        builders = [lambda w=w: hip.pack_conv_k3(w.detach(), dtype, vol=(2, 32, 32, 32)) for w in ws[:3]]
+        builders += [lambda w=ws[3]: hip.pack_conv_k1(w.detach().reshape(3, 32), dtype), lambda w=ws[4]: hip.pack_conv_gather(w.detach(), dtype)]
+        first = [c.get(w, dtype, "f", b).clone() for c, w, b in zip(caches, ws, builders)]
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(-0.5)          # in-place edit: every image is stale now
+        got = [c.get(w, dtype, "f", b) for c, w, b in zip(caches, ws, builders)]   # ONE batched refresh on the first get
+        for g, f, b in zip(got, first, builders):
+            ref = b()
+            assert torch.equal(g, ref) and not torch.equal(g, f)
+
+
+def test_conv3d_k3_kernel_choice():
+    from medicalsemseg_amd import hip
+    _dev()
+    L = hip.lib()
+    assert L.msseg_conv3d_k3_kernel(2, 96, 96, 96, 32, 32, hip.BF16) == 3      # ping-pong kernel
+    assert L.msseg_conv3d_k3_kernel(2, 96, 96, 96, 32, 32, hip.F32) == 0       # fp32: generic big tile
+    assert L.msseg_conv3d_k3_kernel(2, 96, 96, 96, 64, 32, hip.BF16) == 0      # two channel blocks per stage
+    assert L.msseg_conv3d_k3_kernel(2, 12, 12, 12, 32, 32, hip.BF16) in (1, 2)  # small grid
+
+
 def test_flat_adamw_matches_torch_adamw():
     """fused flat-buffer AdamW (+ weight-decay grouping, + folded gradient clipping) vs torch.optim.AdamW"""
     from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay
