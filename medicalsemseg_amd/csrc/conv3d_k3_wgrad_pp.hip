@@ -124,13 +124,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3wg_pp_kernel(const K3WgParams p
         const int td = tv / (TH * TW), th = (tv / TW) % TH, tw = tv % TW;
         p_off[j] = (unsigned)((((long long)td * p.H + th) * p.W + tw) * p.ldp * 2 + lchunk * 16);
     }
+    // channel chunks beyond the tensor's channel count (last block of a count that is not a multiple of 32) read zeros
+    const bool p_cok = mblk * 32 + lchunk * 8 < p.M, q_cok = kblk * 32 + lchunk * 8 < p.K;
+    const bool chunks_full = (mblk + 1) * 32 <= p.M && (kblk + 1) * 32 <= p.K;
     auto load_tile = [&](const TileCo& tc) {
         const int dB = tc.d0 - 1, hB = tc.h0 - 1, wB = tc.w0 - 1;
         const long long qvox = (((long long)tc.n * p.D + dB) * p.H + hB) * p.W + wB;
         const long long pvox = (((long long)tc.n * p.D + tc.d0) * p.H + tc.h0) * p.W + tc.w0;
         const unsigned char* qb = qg + qvox * p.ldq * 2;
         const unsigned char* pb = pg + pvox * p.ldp * 2;
-        const bool interior = dB >= 0 && dB + PD <= p.D && hB >= 0 && hB + PH <= p.H && wB >= 0 && wB + PW <= p.W;
+        const bool interior = chunks_full && dB >= 0 && dB + PD <= p.D && hB >= 0 && hB + PH <= p.H && wB >= 0 && wB + PW <= p.W;
         if (interior) {
 #pragma unroll
             for (int j = 0; j < NIQ_W; ++j) {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3wg_pp_kernel(const K3WgParams p
                 const int it = wq + 4 * j;
                 const int hv = it * 16 + lrow;
                 const int hd = hv / (PH * PWP), rem = hv - hd * (PH * PWP), hh = rem / PWP, hw = rem - hh * PWP;
-                const bool inb = (unsigned)(dB + hd) < (unsigned)p.D && (unsigned)(hB + hh) < (unsigned)p.H &&
+                const bool inb = q_cok && (unsigned)(dB + hd) < (unsigned)p.D && (unsigned)(hB + hh) < (unsigned)p.H &&
                                  (unsigned)(wB + hw) < (unsigned)p.W;
                 const unsigned char* src = inb ? qb + q_off[j] : zsrc;
                 if (q_off[j] != SKIP) glds16(src, ldsQ + it * 1024);
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3wg_pp_kernel(const K3WgParams p
             for (int j = 0; j < NIP_W; ++j) {
                 const int tv = (wq + 4 * j) * 16 + lrow;
                 const int td = tv / (TH * TW), th = (tv / TW) % TH, tw = tv % TW;
-                const bool inb = tc.d0 + td < p.D && tc.h0 + th < p.H && tc.w0 + tw < p.W;
+                const bool inb = p_cok && tc.d0 + td < p.D && tc.h0 + th < p.H && tc.w0 + tw < p.W;
                 const unsigned char* src = inb ? pb + p_off[j] : zsrc;
                 glds16(src, ldsP + (wq + 4 * j) * 1024);
             }
@@ -282,17 +285,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3wg_pp_kernel(const K3WgParams p
 bool msseg_k3wg_pp_eligible(const K3WgParams& p) {
     static const bool off = getenv("MSSEG_NO_K3PP") != nullptr;
     if (off) return false;
-    if (p.M % 32 || p.K % 32) return false;
+    if (p.M % 8 || p.K % 8) return false;   // 16-byte channel chunks; partial 32-blocks are zero-filled
     if ((p.ldp % 8) || (p.ldq % 8) || ((uintptr_t)p.pten & 15) || ((uintptr_t)p.qten & 15)) return false;
     const long long ldm = p.ldp > p.ldq ? p.ldp : p.ldq;
     if ((long long)(PD + 1) * p.H * p.W * ldm * 2 >= 0x7fffffffLL) return false;   // 32-bit tile-relative offsets
     const long long tiles = (long long)p.N * ceil_div(p.D, TD) * ceil_div(p.H, TH) * ceil_div(p.W, TW);
     if (tiles > 0x7fffffffLL) return false;
-    return tiles * (p.M / 32) * (p.K / 32) >= 2LL * msseg_num_cus();
+    return tiles * ceil_div(p.M, 32) * ceil_div(p.K, 32) >= 2LL * msseg_num_cus();
 }
 
 int msseg_k3wg_pp_grid(const K3WgParams& p) {
-    const int pairs = (p.M / 32) * (p.K / 32);
+    const int pairs = ceil_div(p.M, 32) * ceil_div(p.K, 32);
     const int tiles = p.N * ceil_div(p.D, TD) * ceil_div(p.H, TH) * ceil_div(p.W, TW);
     int gx = msseg_num_cus() / pairs;
     gx &= ~7;
@@ -314,7 +317,7 @@ int msseg_k3wg_pp_launch(const K3WgParams& p, int gx, hipStream_t stream) {
             MSSEG_FAIL(MSSEG_ELAUNCH, "conv3d_k3_wgrad_pp: cannot set dynamic LDS size %d", lds);
         attr_set = true;
     }
-    const int pairs = (p.M / 32) * (p.K / 32);
+    const int pairs = ceil_div(p.M, 32) * ceil_div(p.K, 32);
     if (timing) hipLaunchKernelGGL(k3wg_pp_kernel<1>, dim3(gx, pairs, 1), dim3(NTHREADS), lds, stream, pl);
     else hipLaunchKernelGGL(k3wg_pp_kernel<0>, dim3(gx, pairs, 1), dim3(NTHREADS), lds, stream, pl);
     MSSEG_CHECK_LAUNCH("conv3d_k3_wgrad_pp");

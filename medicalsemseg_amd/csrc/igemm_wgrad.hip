@@ -479,9 +479,9 @@ template <typename T> int launch_wg_k3(WgradParams& p, ReduceParams& rp, void* w
         // large grids with 32-multiple channel counts: the ping-pong kernel (conv3d_k3_wgrad_pp.hip)
         K3WgParams pp{};
         pp.pten = p.pten; pp.ldp = p.ldp; pp.qten = p.qten; pp.ldq = p.ldq;
-        pp.N = p.N; pp.D = p.D; pp.H = p.H; pp.W = p.W; pp.M = p.M; pp.K = p.K; pp.kblks = p.K / 32;
+        pp.N = p.N; pp.D = p.D; pp.H = p.H; pp.W = p.W; pp.M = p.M; pp.K = p.K; pp.kblks = ceil_div(p.K, 32);
         if (msseg_k3wg_pp_eligible(pp)) {
-            const int pairs = (p.M / 32) * (p.K / 32);
+            const int pairs = ceil_div(p.M, 32) * ceil_div(p.K, 32);
             int gx = msseg_k3wg_pp_grid(pp);
             const long long fit = (long long)(wsb / ((size_t)27 * 32 * 32 * 4 * pairs));
             if (fit >= 8) {
@@ -490,7 +490,7 @@ template <typename T> int launch_wg_k3(WgradParams& p, ReduceParams& rp, void* w
                 const int rc = msseg_k3wg_pp_launch(pp, gx, st);
                 if (rc) return rc;
                 rp.slabs = pp.slabs;
-                rp.mblks = p.M / 32; rp.kblks = p.K / 32; rp.nslots = gx; rp.cbw = 32;
+                rp.mblks = ceil_div(p.M, 32); rp.kblks = ceil_div(p.K, 32); rp.nslots = gx; rp.cbw = 32;
                 return launch_reduce(rp, st);
             }
         }

@@ -52,7 +52,9 @@ def gen(*shape, seed=0, scale=1.0):
                                          (48, 48, (12, 12, 24)), (16, 16, (8, 8, 8)), (128, 256, (6, 6, 6)),
                                          (96, 48, (6, 10, 18)), (8, 24, (5, 7, 9)),
                                          # grids large enough for the ping-pong kernel (bf16, 32 channels per stage)
-                                         (32, 32, (32, 48, 64)), (32, 64, (30, 29, 70)), (64, 32, (34, 31, 50))])
+                                         (32, 32, (32, 48, 64)), (32, 64, (30, 29, 70)), (64, 32, (34, 31, 50)),
+                                         # 48-channel layers (Swin-UNETR decoder): partial 32-blocks in the ping-pong wgrad
+                                         (48, 48, (32, 32, 64)), (96, 48, (30, 33, 36))])
 def test_conv3d_k3_fwd_dgrad_wgrad(dtype, cin, cout, sp):
     from medicalsemseg_amd import hip
     from medicalsemseg_amd.layers import Conv3
