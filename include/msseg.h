@@ -122,6 +122,20 @@ int msseg_deconv_k2s2_fwd(const void* x, long long ldx, const void* wp, const fl
 /* input gradient of the above: dy [N,2D,2H,2W,Cout] -> dx [N,D,H,W,Cin]. */
 int msseg_deconv_k2s2_bwd_data(const void* dy, long long lddy, const void* wp, void* dx, long long lddx,
                                int N, int D, int H, int W, int Cin, int Cout, int dtype, msseg_stream_t stream);
+/* The two flat input-gradient kernels with the InstanceNorm-backward sums of the RECEIVING layer fused into the epilogue
+ * (arguments as msseg_conv3d_k3_dgrad_inbwd): the gradient that reaches the second conv+norm unit of a UNet level comes
+ * from the 1x1x1 output conv (level 0) or from a transposed conv (other decoder levels / the bottleneck).
+ * k1: dy [N*S, Cin] -> da [N*S, Cout], S voxels per sample.  deconv: dy [N,2D,2H,2W,Cout] -> dx [N,D,H,W,Cin]. */
+int msseg_conv3d_k1_dgrad_inbwd(const void* dy, long long lddy, const void* wp, void* da, long long ldda, int N,
+                                long long S, int Cin, int Cout, const void* yraw, long long ldyraw, const void* act,
+                                long long ldact, const float* fwd_stats, float slope, float eps, float* red,
+                                float* dgamma, float* dbeta, int accumulate, void* scratch, size_t scratch_bytes,
+                                int dtype, msseg_stream_t stream);
+int msseg_deconv_k2s2_bwd_data_inbwd(const void* dy, long long lddy, const void* wp, void* dx, long long lddx, int N,
+                                     int D, int H, int W, int Cin, int Cout, const void* yraw, long long ldyraw,
+                                     const void* act, long long ldact, const float* fwd_stats, float slope, float eps,
+                                     float* red, float* dgamma, float* dbeta, int accumulate, void* scratch,
+                                     size_t scratch_bytes, int dtype, msseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradients (fp32 output in the torch parameter layout; deterministic two-stage reduction).

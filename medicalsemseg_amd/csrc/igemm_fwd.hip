@@ -218,7 +218,7 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
         } else {  // SRC_DECONV_BWD: coarse voxel gathers its 8 fine children
             const int cv = tc.w0 + hv;
             if (cv < p.W && c < p.K) {
-                int tt = cv;
+                int tt = tc.n * p.W + cv;   // flat index over all samples (p.N == 1: tc.n == 0)
                 const int cw = tt % p.OW; tt /= p.OW;
                 const int ch = tt % p.OH; tt /= p.OH;
                 const int cd = tt % p.OD; const int nn = tt / p.OD;
@@ -1018,6 +1018,72 @@ int msseg_deconv_k2s2_bwd_data(const void* dy, long long lddy, const void* wp, v
     p.x = dy; p.ldx = lddy; p.wp = wp; p.bias = nullptr; p.y = dx; p.ldy = lddx;
     p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = 8 * Cout; p.M = Cin;
     p.OD = D; p.OH = H; p.OW = W; p.creal = Cout;
+    return dtype == MSSEG_F32 ? launch_flat<float, SRC_DECONV_BWD, EPI_STORE>(p, (hipStream_t)stream)
+                              : launch_flat<bf16_t, SRC_DECONV_BWD, EPI_STORE>(p, (hipStream_t)stream);
+}
+
+// ---- flat (1x1x1-tap) input-gradient kernels with the InstanceNorm-backward sums of the receiving layer fused into the
+// epilogue, as msseg_conv3d_k3_dgrad_inbwd: the grid is tiled per sample (N samples of S voxels) so that a tile never
+// straddles two samples.
+static int flat_inbwd_common(IgemmParams& p, int N, long long S, int Cout, const void* yraw, long long ldyraw,
+                             const void* act, long long ldact, const float* fwd_stats, float slope, float eps, float* red,
+                             float* dgamma, float* dbeta, int accumulate, void* scratch, size_t scratch_bytes, int esz,
+                             const char* who) {
+    if (!yraw || !act || !fwd_stats || !red) MSSEG_FAIL(MSSEG_EINVAL, "%s: null pointer", who);
+    if ((dgamma == nullptr) != (dbeta == nullptr)) MSSEG_FAIL(MSSEG_EINVAL, "%s: dgamma/dbeta go together", who);
+    if (N < 1 || N > MSSEG_STATS_NMAX || S < 1 || S > 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "%s: 1 <= N <= %d samples", who, MSSEG_STATS_NMAX);
+    if (Cout % 4 || (ldyraw % 4) || (ldact % 4) || ((uintptr_t)yraw % (4 * esz)) || ((uintptr_t)act % (4 * esz)))
+        MSSEG_FAIL(MSSEG_EINVAL, "%s: channel count / strides must be multiples of 4", who);
+    if (Cout > 64 * 16) MSSEG_FAIL(MSSEG_EINVAL, "%s: at most 1024 output channels", who);
+    if (!scratch || ((uintptr_t)scratch & 255) || scratch_bytes < msseg_reduce_scratch_bytes())
+        MSSEG_FAIL(MSSEG_EWORKSPACE, "%s: needs a scratch of %zu bytes", who, msseg_reduce_scratch_bytes());
+    p.N = N; p.D = 1; p.H = 1; p.W = (int)S;
+    p.stats = red;
+    p.counter = (unsigned int*)scratch;
+    p.stats_ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+    p.nb_y = yraw; p.nb_ldy = ldyraw; p.nb_a = act; p.nb_lda = ldact; p.nb_stats = fwd_stats;
+    p.nb_slope = slope; p.nb_eps = eps; p.nb_S = S;
+    p.nb_dgamma = dgamma; p.nb_dbeta = dbeta; p.nb_acc = accumulate;
+    return MSSEG_OK;
+}
+
+int msseg_conv3d_k1_dgrad_inbwd(const void* dy, long long lddy, const void* wp, void* da, long long ldda, int N,
+                                long long S, int Cin, int Cout, const void* yraw, long long ldyraw, const void* act,
+                                long long ldact, const float* fwd_stats, float slope, float eps, float* red,
+                                float* dgamma, float* dbeta, int accumulate, void* scratch, size_t scratch_bytes,
+                                int dtype, msseg_stream_t stream) {
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    int rc = check_common(dy, lddy, wp, da, ldda, dtype, esz);
+    if (rc) return rc;
+    if (Cin < 1 || Cout < 1 || Cin % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_dgrad_inbwd: bad channel counts");
+    IgemmParams p{};
+    p.x = dy; p.ldx = lddy; p.wp = wp; p.bias = nullptr; p.y = da; p.ldy = ldda;
+    p.K = Cin; p.M = Cout;
+    rc = flat_inbwd_common(p, N, S, Cout, yraw, ldyraw, act, ldact, fwd_stats, slope, eps, red, dgamma, dbeta, accumulate,
+                           scratch, scratch_bytes, esz, "conv3d_k1_dgrad_inbwd");
+    if (rc) return rc;
+    return dtype == MSSEG_F32 ? launch_flat<float, SRC_DIRECT, EPI_STORE>(p, (hipStream_t)stream)
+                              : launch_flat<bf16_t, SRC_DIRECT, EPI_STORE>(p, (hipStream_t)stream);
+}
+
+int msseg_deconv_k2s2_bwd_data_inbwd(const void* dy, long long lddy, const void* wp, void* dx, long long lddx, int N,
+                                     int D, int H, int W, int Cin, int Cout, const void* yraw, long long ldyraw,
+                                     const void* act, long long ldact, const float* fwd_stats, float slope, float eps,
+                                     float* red, float* dgamma, float* dbeta, int accumulate, void* scratch,
+                                     size_t scratch_bytes, int dtype, msseg_stream_t stream) {
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    int rc = check_common(dy, lddy, wp, dx, lddx, dtype, esz);
+    if (rc) return rc;
+    if (Cout % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_data_inbwd: Cout %% %d must be 0", 16 / esz);
+    const long long S = (long long)D * H * W;
+    if ((long long)N * S > 0x7fffffffLL / 8) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_data_inbwd: bad voxel count");
+    IgemmParams p{};
+    p.x = dy; p.ldx = lddy; p.wp = wp; p.bias = nullptr; p.y = dx; p.ldy = lddx;
+    p.K = 8 * Cout; p.M = Cin;
+    p.OD = D; p.OH = H; p.OW = W; p.creal = Cout;
+    rc = flat_inbwd_common(p, N, S, Cin, yraw, ldyraw, act, ldact, fwd_stats, slope, eps, red, dgamma, dbeta, accumulate,
+                           scratch, scratch_bytes, esz, "deconv_k2s2_bwd_data_inbwd");
+    if (rc) return rc;
     return dtype == MSSEG_F32 ? launch_flat<float, SRC_DECONV_BWD, EPI_STORE>(p, (hipStream_t)stream)
                               : launch_flat<bf16_t, SRC_DECONV_BWD, EPI_STORE>(p, (hipStream_t)stream);
 }

@@ -38,6 +38,10 @@ SIGNATURES = {
     "msseg_reduce_scratch_bytes": ([], _sz),
     "msseg_conv3d_k3_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll, _vp, _f, _f, _vp,
                                      _vp, _vp, _i, _vp, _sz, _i, _vp], _i),
+    "msseg_conv3d_k1_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _ll, _i, _i, _vp, _ll, _vp, _ll, _vp, _f, _f, _vp,
+                                     _vp, _vp, _i, _vp, _sz, _i, _vp], _i),
+    "msseg_deconv_k2s2_bwd_data_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll, _vp, _f, _f,
+                                          _vp, _vp, _vp, _i, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_k3s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_zero_stuff2": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_window_attention_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -338,6 +342,35 @@ def conv3d_k1(x, wp, bias, y, cin, cout):
     _ck(lib().msseg_conv3d_k1_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), nv, cin, cout, dt(x), _stream()),
         "conv3d_k1_fwd")
     return y
+
+
+def conv3d_k1_dgrad_inbwd(dy, wp, da, cin, cout, yraw, act, fwd_stats, slope, eps, dgamma=None, dbeta=None,
+                          accumulate=False):
+    """da = dy @ W (1x1x1 input gradient, cin = channels of dy, cout = channels of da) + the InstanceNorm-backward sums of
+    the layer (yraw, act, fwd_stats) that receives da, in one launch.  Returns red[N][cout][2]."""
+    _need_gpu(dy, wp, da, yraw, act, fwd_stats)
+    N = da.shape[0]
+    S = da.numel() // (N * da.shape[-1])
+    red = torch.empty(N, cout, 2, dtype=torch.float32, device=dy.device)
+    sc = scratch(dy.device)
+    _ck(lib().msseg_conv3d_k1_dgrad_inbwd(_p(dy), ld(dy), _p(wp), _p(da), ld(da), N, S, cin, cout, _p(yraw), ld(yraw),
+                                          _p(act), ld(act), _p(fwd_stats), slope, eps, _p(red), _p(dgamma), _p(dbeta),
+                                          int(accumulate), _p(sc), sc.numel(), dt(dy), _stream()), "conv3d_k1_dgrad_inbwd")
+    return red
+
+
+def deconv_k2s2_bwd_data_inbwd(dy, wp, dx, cin, cout, yraw, act, fwd_stats, slope, eps, dgamma=None, dbeta=None,
+                               accumulate=False):
+    """dx of ConvTranspose3d k2 s2 + the InstanceNorm-backward sums of the layer that receives dx.  Returns red[N][cin][2]."""
+    _need_gpu(dy, wp, dx, yraw, act, fwd_stats)
+    N, D, H, W = dx.shape[:4]
+    red = torch.empty(N, cin, 2, dtype=torch.float32, device=dy.device)
+    sc = scratch(dy.device)
+    _ck(lib().msseg_deconv_k2s2_bwd_data_inbwd(_p(dy), ld(dy), _p(wp), _p(dx), ld(dx), N, D, H, W, cin, cout, _p(yraw),
+                                               ld(yraw), _p(act), ld(act), _p(fwd_stats), slope, eps, _p(red),
+                                               _p(dgamma), _p(dbeta), int(accumulate), _p(sc), sc.numel(), dt(dy),
+                                               _stream()), "deconv_k2s2_bwd_data_inbwd")
+    return red
 
 
 def conv3d_gather(x, wp, bias, y, cin, cout, k, s, p):

@@ -194,6 +194,15 @@ def _empty_like_vol(x, C, dtype=None):
     return torch.empty(x.shape[:-1] + (C,), dtype=dtype or x.dtype, device=x.device)
 
 
+def _norm_grad_bufs(nrm):
+    """(dgamma, dbeta, accumulate) buffers of an InstNormAct for the fused InstanceNorm-backward epilogues"""
+    if nrm.gamma is not None and nrm.gamma.requires_grad:
+        dg, acc = _grad_buf(nrm.gamma)
+        db, _ = _grad_buf(nrm.beta)
+        return dg, db, acc
+    return None, None, False
+
+
 class Conv3:
     """3x3x3 s1 p1 convolution (+bias).  Few-input-channel layers go through the gather kernel."""
 
@@ -299,8 +308,10 @@ class Conv1:
             return y, hip.channel_stats(y)
         return y
 
-    def bwd(self, x, dy, need_dx=True, dy_channels=None):
-        """dy may carry zero-padded channels (dy_channels = padded count, multiple of 8)."""
+    def bwd(self, x, dy, need_dx=True, dy_channels=None, next_norm=None):
+        """dy may carry zero-padded channels (dy_channels = padded count, multiple of 8).
+        next_norm = (InstNormAct, yraw, stats, act) of the layer whose activation is this conv's input: its
+        InstanceNorm-backward sums are then fused into the input-gradient kernel; returns (dx, red)."""
         dtype = x.dtype
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
@@ -319,7 +330,16 @@ class Conv1:
                             lambda: hip.pack_conv_k1(self.w.detach().reshape(self.cout, self.cin), dtype, dgrad=True))
         dx = _empty_like_vol(dy, self.cin)
         kpad = dy_channels if dy_channels is not None else self.cout
-        hip.conv3d_k1(dy if dy_channels is None else dy[..., :kpad], wp, None, dx, kpad, self.cin)
+        dyk = dy if dy_channels is None else dy[..., :kpad]
+        if next_norm is not None:
+            nrm, yraw, stats, act = next_norm
+            if dy.shape[0] <= 8 and self.cin % 4 == 0:
+                dg, db, acc = _norm_grad_bufs(nrm)
+                red = hip.conv3d_k1_dgrad_inbwd(dyk, wp, dx, kpad, self.cin, yraw, act, stats, nrm.slope, nrm.eps, dg, db, acc)
+                return dx, red
+            hip.conv3d_k1(dyk, wp, None, dx, kpad, self.cin)
+            return dx, None
+        hip.conv3d_k1(dyk, wp, None, dx, kpad, self.cin)
         return dx
 
 
@@ -339,7 +359,9 @@ class Deconv2:
         hip.deconv_k2s2(x, wp, self.b, y, self.cin, self.cout)
         return y
 
-    def bwd(self, x, dy, need_dx=True):
+    def bwd(self, x, dy, need_dx=True, next_norm=None):
+        """next_norm = (InstNormAct, yraw, stats, act) of the layer whose activation `x` is: its InstanceNorm-backward sums
+        are fused into the input-gradient kernel; returns (dx, red)."""
         dtype = x.dtype
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
@@ -351,6 +373,15 @@ class Deconv2:
             return None
         wp = self.cache.get(self.w, dtype, "d", lambda: hip.pack_deconv(self.w.detach(), dtype, bwd=True))
         dx = torch.empty_like(x, memory_format=torch.contiguous_format)
+        if next_norm is not None:
+            nrm, yraw, stats, act = next_norm
+            if dy.shape[0] <= 8 and self.cin % 4 == 0:
+                dg, db, acc = _norm_grad_bufs(nrm)
+                red = hip.deconv_k2s2_bwd_data_inbwd(dy, wp, dx, self.cin, self.cout, yraw, act, stats, nrm.slope, nrm.eps,
+                                                     dg, db, acc)
+                return dx, red
+            hip.deconv_k2s2_bwd_data(dy, wp, dx, self.cin, self.cout)
+            return dx, None
         hip.deconv_k2s2_bwd_data(dy, wp, dx, self.cin, self.cout)
         return dx
 

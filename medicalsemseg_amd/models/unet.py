@@ -193,7 +193,19 @@ class _UNetFn(torch.autograd.Function):
     def _backward_body(ctx, net, saved, dl, f, n_in):
         side = layers.WGRAD_SIDE
         side.set_mode(side.DEFER if os.environ.get("MSSEG_WGRAD_STREAM") == "defer" else side.INLINE)
-        g = net._final.bwd(ctx.last, dl, True, dy_channels=LOGIT_LD)
+        # Every gradient that reaches the second conv+norm unit of a level comes from a flat input-gradient kernel (the
+        # 1x1x1 output conv, a transposed conv): those kernels also produce the unit's InstanceNorm-backward sums
+        # (`red_c1`), which saves its separate reduction pass over three full tensors.
+        def unit_norm(cna, sv):
+            if os.environ.get("MSSEG_NO_FLAT_INBWD"):    # A/B switch: separate reduction pass
+                return None
+            return (cna.norm, sv[1], sv[2], sv[3])      # (InstNormAct, yraw, stats, act) of a ConvNormAct's saved tuple
+
+        def pair(r):                                     # (dx, red) with or without the fused sums
+            return r if isinstance(r, tuple) else (r, None)
+
+        g, red_c1 = pair(net._final.bwd(ctx.last, dl, True, dy_channels=LOGIT_LD,
+                                        next_norm=unit_norm(net._dec[3][2], saved["dec"][3][2])))
         skip_grads = [None] * 4
         for j in range(3, -1, -1):  # decoder levels 0..3 in reverse order of execution
             up, c0, c1 = net._dec[j]
@@ -202,10 +214,11 @@ class _UNetFn(torch.autograd.Function):
                 side.flush()
                 side.set_mode(side.SIDE)
             up_in, s0, s1 = saved["dec"][j]
-            g, red = c1.bwd(s1, g, True, next_saved=s0, next_cna=c0)
+            g, red = c1.bwd(s1, g, True, red=red_c1, next_saved=s0, next_cna=c0)
             dcat = c0.bwd(s0, g, True, red=red)
             skip_grads[lvl] = dcat[..., :f[lvl]]
-            g = up.bwd(up_in, dcat[..., f[lvl]:], True)
+            below = unit_norm(net._dec[j - 1][2], saved["dec"][j - 1][2]) if j > 0 else unit_norm(net._enc[4][1], saved["enc"][4][1])
+            g, red_c1 = pair(up.bwd(up_in, dcat[..., f[lvl]:], True, next_norm=below))
         # encoder, bottom-up
         for lvl in range(4, -1, -1):
             c0, c1 = net._enc[lvl]
@@ -217,7 +230,7 @@ class _UNetFn(torch.autograd.Function):
                 x_l = s1[3]
                 hip.maxpool2_bwd(x_l, g, skip_grads[lvl], accumulate=True)
                 g = skip_grads[lvl]
-            g, red = c1.bwd(s1, g, True, next_saved=s0, next_cna=c0)
+            g, red = c1.bwd(s1, g, True, red=(red_c1 if lvl == 4 else None), next_saved=s0, next_cna=c0)
             g = c0.bwd(s0, g, need_dx=(lvl > 0), red=red)
         ctx.saved = None
         return (None,) * n_in
