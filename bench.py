@@ -154,7 +154,7 @@ def main():
         enc = SwinTransformerNNFormer((args.size,) * 3, (2, 2, 2), 1, 48, (2, 2, 2, 2), (3, 6, 12, 24), (6, 6, 6, 3),
                                       drop_path_rate=0.0, compute_dtype=dtype)
         net = SwinUNETRCustom(enc, 1, args.classes, (args.size,) * 3, 48, (2, 2, 2), compute_dtype=dtype).to(dev)
-        args.no_graph = True
+        args.no_graph = args.no_graph or bool(os.environ.get("MSSEG_SWIN_NO_GRAPH"))
     else:
         net = UNet(1, args.classes, compute_dtype=dtype).to(dev)
     opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=4e-4, betas=(0.9, 0.95), eps=1e-6)

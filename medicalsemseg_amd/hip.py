@@ -706,7 +706,7 @@ def layernorm_fwd(x, gamma, beta, y, eps=1e-5, save=True):
     return mean, rstd
 
 
-def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma=None, dbeta=None):
+def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma=None, dbeta=None, accumulate=False):
     _need_gpu(x, dy, dx)
     Cc = x.shape[-1]
     rows = x.numel() // Cc
@@ -714,7 +714,8 @@ def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma=None, dbeta=None):
                                   rows, Cc, dt(x), _stream()), "layernorm_bwd")
     if dgamma is not None:
         sc = scratch(x.device)
-        _ck(lib().msseg_layernorm_param_grad(_p(x), ld(x), _p(mean), _p(rstd), _p(dy), ld(dy), _p(dgamma), _p(dbeta), 0,
+        _ck(lib().msseg_layernorm_param_grad(_p(x), ld(x), _p(mean), _p(rstd), _p(dy), ld(dy), _p(dgamma), _p(dbeta),
+                                             int(accumulate),
                                              rows, Cc, _p(sc), sc.numel(), dt(x), _stream()), "layernorm_param_grad")
     return dx
 

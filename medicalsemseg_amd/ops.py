@@ -10,6 +10,13 @@ import torch
 
 from . import hip, layers
 
+def _gbuf(p):
+    """Parameter gradients are written (or accumulated) in place into `p.grad` by the kernels and the autograd functions
+    return None for them: no AccumulateGrad nodes, no extra add kernels, and the step stays hipGraph-capturable
+    (as the whole-network functions of layers.py do)."""
+    return layers._grad_buf(p)
+
+
 def _packed(weight, dtype, kind, builder):
     """packed-weight images live on the parameter object: built once, refreshed by the batched repack of
     layers.PACK_REGISTRY after each optimiser step (instead of one pack launch per forward / backward call)"""
@@ -35,28 +42,29 @@ class LinearFn(torch.autograd.Function):
         wp = _packed(weight, T, "f", lambda: hip.pack_conv_k1(weight.detach().contiguous(), T))
         y = torch.empty(x.shape[:-1] + (cout,), dtype=T, device=x.device)
         hip.conv3d_k1(x, wp, bias, y, cin, cout)
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x)
+        ctx.weight, ctx.bias = weight, bias
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
         dy = _c(dy)
         cout, cin = weight.shape
         T = x.dtype
-        dx = dw = db = None
+        dx = None
         if ctx.needs_input_grad[0]:
             wpd = _packed(weight, T, "d", lambda: hip.pack_conv_k1(weight.detach().contiguous(), T, dgrad=True))
             dx = torch.empty_like(x)
             hip.conv3d_k1(dy, wpd, None, dx, cout, cin)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            hip.conv3d_k1_wgrad(x, dy, dw, cin, cout)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(cout, dtype=torch.float32, device=x.device)
-            hip.channel_sum(dy, db)
-        return dx, dw, db
+            g, acc = _gbuf(weight)
+            hip.conv3d_k1_wgrad(x, dy, g, cin, cout, acc)
+        if bias is not None and ctx.needs_input_grad[2]:
+            g, acc = _gbuf(bias)
+            hip.channel_sum(dy, g, acc)
+        return dx, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -65,18 +73,23 @@ class LayerNormFn(torch.autograd.Function):
         x = _c(x)
         y = torch.empty_like(x)
         mean, rstd = hip.layernorm_fwd(x, gamma, beta, y, eps)
-        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta = gamma, beta
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mean, rstd = ctx.saved_tensors
+        x, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.gamma, ctx.beta
         dy = _c(dy)
         dx = torch.empty_like(x)
-        dg = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
-        db = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
-        hip.layernorm_bwd(x, gamma, mean, rstd, dy, dx, dg, db)
-        return dx, dg, db, None
+        dg = db = None
+        acc = False
+        if ctx.needs_input_grad[1]:
+            dg, acc = _gbuf(gamma)
+            db, _ = _gbuf(beta)
+        hip.layernorm_bwd(x, gamma, mean, rstd, dy, dx, dg, db, acc)
+        return dx, None, None, None
 
 
 class GeluFn(torch.autograd.Function):
@@ -116,6 +129,7 @@ class WindowAttnFn(torch.autograd.Function):
         lse = hip.window_attention_fwd(qkv, qb, tab, out, heads, ws, shift)
         ctx.save_for_backward(qkv, qb, tab, out, lse)
         ctx.cfg = (heads, ws, shift)
+        ctx.table = table
         return out
 
     @staticmethod
@@ -123,10 +137,18 @@ class WindowAttnFn(torch.autograd.Function):
         qkv, qb, tab, out, lse = ctx.saved_tensors
         heads, ws, shift = ctx.cfg
         dqkv = torch.empty_like(qkv)
-        dtable = torch.zeros_like(tab) if ctx.needs_input_grad[2] else None
+        dtable = None
+        if ctx.needs_input_grad[2]:
+            table = ctx.table
+            if table.is_contiguous():
+                dtable, acc = _gbuf(table)       # the kernel adds into the buffer
+                if not acc:
+                    dtable.zero_()
+            else:
+                dtable = torch.zeros_like(tab)
         hip.window_attention_bwd(qkv, qb, tab, out, lse, _c(dout), dqkv, dtable, heads, ws, shift)
         # gradient w.r.t. qkv_bias through PADDED tokens (only when the grid is not a window multiple) is dropped
-        return dqkv, None, dtable, None, None, None
+        return dqkv, None, (None if ctx.table.is_contiguous() else dtable), None, None, None
 
 
 class Conv3Fn(torch.autograd.Function):
@@ -147,25 +169,26 @@ class Conv3Fn(torch.autograd.Function):
             wp = _packed(weight, T, "f2", lambda: hip.pack_conv_k3(weight.detach().contiguous(), T))
             y = torch.empty(B, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1, cout, dtype=T, device=x.device)
             hip.conv3d_k3s2(x, wp, bias, y, cin, cout)
-        ctx.save_for_backward(x, weight)
-        ctx.stride, ctx.has_bias = stride, bias is not None
+        ctx.save_for_backward(x)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.stride = stride
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
         dy = _c(dy)
         cout, cin = weight.shape[0], weight.shape[1]
         T = x.dtype
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(cout, dtype=torch.float32, device=x.device)
-            hip.channel_sum(dy, db)
+        if bias is not None and ctx.needs_input_grad[2]:
+            g, acc = _gbuf(bias)
+            hip.channel_sum(dy, g, acc)
         if ctx.stride == 2:   # stride-1 problems on the zero-stuffed gradient
             dyz = torch.empty(x.shape[:-1] + (cout,), dtype=T, device=x.device)
             hip.zero_stuff2(dy, dyz)
             dy = dyz
-        dx = dw = None
+        dx = None
         if ctx.needs_input_grad[0]:
             dvol = tuple(dy.shape[:4])
             wpd = _packed(weight, T, ("d", dvol),
@@ -173,9 +196,9 @@ class Conv3Fn(torch.autograd.Function):
             dx = torch.empty_like(x)
             hip.conv3d_k3(dy, wpd, None, dx, cout, cin)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            hip.conv3d_k3_wgrad(x, dy, dw, cin, cout)
-        return dx, dw, db, None
+            g, acc = _gbuf(weight)
+            hip.conv3d_k3_wgrad(x, dy, g, cin, cout, acc)
+        return dx, None, None, None
 
 
 class PatchConvFn(torch.autograd.Function):
@@ -190,25 +213,26 @@ class PatchConvFn(torch.autograd.Function):
         wp = _packed(weight, T, "g", lambda: hip.pack_conv_gather(weight.detach().contiguous(), T))
         y = torch.empty(B, D // k, H // k, W // k, cout, dtype=T, device=x.device)
         hip.conv3d_gather(x, wp, bias, y, cin, cout, k, k, 0)
-        ctx.save_for_backward(x, weight)
-        ctx.k, ctx.has_bias = k, bias is not None
+        ctx.save_for_backward(x)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.k = k
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
         dy = _c(dy)
         cout, cin = weight.shape[0], weight.shape[1]
-        dw = db = None
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            hip.conv3d_gather_wgrad(x, dy, dw, cin, cout, ctx.k, ctx.k, 0)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(cout, dtype=torch.float32, device=x.device)
-            hip.channel_sum(dy, db)
+            g, acc = _gbuf(weight)
+            hip.conv3d_gather_wgrad(x, dy, g, cin, cout, ctx.k, ctx.k, 0, acc)
+        if bias is not None and ctx.needs_input_grad[2]:
+            g, acc = _gbuf(bias)
+            hip.channel_sum(dy, g, acc)
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("gradient w.r.t. the input volume is not needed on this path")
-        return None, dw, db, None
+        return None, None, None, None
 
 
 def linear(x, weight, bias=None):
