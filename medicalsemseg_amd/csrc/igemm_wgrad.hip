@@ -336,23 +336,38 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
             }
         }
     }
-    // ---- write this workgroup's (wave's) partial slab ----
-    const int nslot_wave = (NTAPS == 27) ? 1 : C::WAVES;
-    const long long slot = (long long)blockIdx.x * nslot_wave + ((NTAPS == 27) ? 0 : wave);
-    const long long nslots = (long long)gridDim.x * nslot_wave;
-    float* slab = p.slabs + ((long long)blockIdx.y * nslots + slot) * C::SLAB_FLOATS;
+    // ---- write this workgroup's partial slab ----
+    // 27 taps: every wave owns different taps of ONE slab.  1 tap (flat kernels): the four waves hold partial sums of the
+    // same CBW x CBW block over different voxels; they are added through LDS (fixed order) so that one slab per workgroup
+    // goes to memory instead of four.
+    float* slab = p.slabs + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * C::SLAB_FLOATS;
     const int r = lane & 15, q = lane >> 4;
+    if constexpr (NTAPS == 27) {
 #pragma unroll
-    for (int tt = 0; tt < TAPW; ++tt) {
-        const int tap = tap0 + tt;
-        if (tap >= NTAPS) break;
+        for (int tt = 0; tt < TAPW; ++tt) {
+            const int tap = tap0 + tt;
+            if (tap >= NTAPS) break;
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+#pragma unroll
+                for (int b = 0; b < CT; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        slab[(tap * CBW + a * 16 + q * 4 + e) * CBW + b * 16 + r] = acc[tt][a][b][e];
+        }
+    } else {
+        __syncthreads();   // operand images are dead
+        float* xch = (float*)smem;
 #pragma unroll
         for (int a = 0; a < CT; ++a)
 #pragma unroll
             for (int b = 0; b < CT; ++b)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    slab[(tap * CBW + a * 16 + q * 4 + e) * CBW + b * 16 + r] = acc[tt][a][b][e];
+                    xch[wave * (CBW * CBW) + (a * 16 + q * 4 + e) * CBW + b * 16 + r] = acc[0][a][b][e];
+        __syncthreads();
+        for (int i = tid; i < CBW * CBW; i += 256)
+            slab[i] = xch[i] + xch[CBW * CBW + i] + xch[2 * CBW * CBW + i] + xch[3 * CBW * CBW + i];
     }
 }
 
@@ -449,7 +464,7 @@ int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes
         p.rel32_ok = ((long long)(C::PD + 1) * p.H * p.W * ldm < 0x7fffffffLL) ? 1 : 0;
     }
     const int pairs = p.mblks * p.kblks;
-    const int wave_slots = (NTAPS == 27) ? 1 : C::WAVES;
+    const int wave_slots = 1;   // one slab per workgroup (the flat kernels add their four waves through LDS)
     const size_t slab_bytes = (size_t)C::SLAB_FLOATS * 4;
     long long gx = msseg_num_cus() * ((C::LDS_BYTES > 80 * 1024) ? 1 : 2);
     if (pairs > 1) gx = (gx + pairs - 1) / pairs;
