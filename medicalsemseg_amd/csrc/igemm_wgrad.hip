@@ -416,25 +416,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceParams p)
 
 // few slabs (small-spatial, many-channel layers): one thread per output, no LDS
 __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const ReduceParams p) {
-    const long long total = (long long)p.M * p.T * p.K;
+    // 32-bit index arithmetic (the host checks M*T*K < 2^31): the 64-bit divisions dominated this kernel
+    const unsigned total = (unsigned)p.M * (unsigned)p.T * (unsigned)p.K;
+    const unsigned K = (unsigned)p.K, T = (unsigned)p.T, cbw = (unsigned)p.cbw, KT = K * T;
     const long long slabf = (long long)p.T * p.cbw * p.cbw;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int k = (int)(i % p.K);
-        const int t = (int)((i / p.K) % p.T);
-        const int m = (int)(i / ((long long)p.K * p.T));
-        const int mb = m / p.cbw, ml = m % p.cbw, kb = k / p.cbw, kl = k % p.cbw;
-        const float* src = p.slabs + ((long long)(mb * p.kblks + kb) * p.nslots) * slabf + ((long long)t * p.cbw + ml) * p.cbw + kl;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned m = i / KT, rem = i - m * KT;
+        const unsigned t = rem / K, k = rem - t * K;
+        const unsigned mb = m / cbw, ml = m - mb * cbw, kb = k / cbw, kl = k - kb * cbw;
+        const float* src = p.slabs + ((long long)(mb * (unsigned)p.kblks + kb) * p.nslots) * slabf + (t * cbw + ml) * cbw + kl;
         float s = 0.f;
 #pragma unroll 8
         for (int sl = 0; sl < p.nslots; ++sl) s += src[(long long)sl * slabf];
-        const long long di = (long long)(m / p.M0) * p.s_m1 + (long long)(m % p.M0) * p.s_m0 + (long long)t * p.s_t +
-                             (long long)(k / p.K0) * p.s_k1 + (long long)(k % p.K0) * p.s_k0;
+        const unsigned m1 = m / (unsigned)p.M0, m0 = m - m1 * (unsigned)p.M0, k1 = k / (unsigned)p.K0, k0 = k - k1 * (unsigned)p.K0;
+        const long long di = (long long)m1 * p.s_m1 + (long long)m0 * p.s_m0 + (long long)t * p.s_t + (long long)k1 * p.s_k1 +
+                             (long long)k0 * p.s_k0;
         p.dw[di] = p.accumulate ? p.dw[di] + s : s;
     }
 }
 
 int launch_reduce(const ReduceParams& rp, hipStream_t stream) {
     const long long total = (long long)rp.M * rp.T * rp.K;
+    if (total >= 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "wgrad: weight tensor too large");
     if (rp.nslots <= 32) {
         int rb = (int)((total + 255) / 256);
         if (rb > 8192) rb = 8192;
