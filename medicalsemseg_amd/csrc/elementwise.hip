@@ -565,14 +565,18 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ x, 
     constexpr int WD = VEC ? DT<T>::EPC : 1;
     const int OD = D / 2, OH = H / 2, OW = W / 2;
     const int groups = (C + WD - 1) / WD;
-    const long long total = (long long)N * OD * OH * OW * groups;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int g = (int)(i % groups);
-        long long t = i / groups;
-        const int ow = (int)(t % OW); t /= OW;
-        const int oh = (int)(t % OH); t /= OH;
-        const int od = (int)(t % OD);
-        const int n = (int)(t / OD);
+    const unsigned total = (unsigned)((long long)N * OD * OH * OW * groups);   // < 2^31: checked by the host wrappers
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        // 32-bit index arithmetic: five 64-bit divisions per thread cost more than the eight loads
+        const unsigned ug = (unsigned)groups;
+        unsigned t = i / ug;
+        const int g = (int)(i - t * ug);
+        unsigned t2 = t / (unsigned)OW;
+        const int ow = (int)(t - t2 * (unsigned)OW);
+        t = t2 / (unsigned)OH;
+        const int oh = (int)(t2 - t * (unsigned)OH);
+        const int n = (int)(t / (unsigned)OD);
+        const int od = (int)(t - (unsigned)n * (unsigned)OD);
         float best[WD];
         int arg[WD];
 #pragma unroll
@@ -949,6 +953,7 @@ int msseg_maxpool2_fwd(const void* x, long long ldx, void* y, long long ldy, int
     const int esz = dtype == MSSEG_F32 ? 4 : 2;
     const bool vec = vec_ok(x, ldx, C, esz) && vec_ok(y, ldy, C, esz);
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * ceil_div(C, vec ? 16 / esz : 1);
+    if (total >= 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "maxpool2_fwd: too many elements");
     const int g = grid_for(total, 1);
 #define MP_F(T_, V_) hipLaunchKernelGGL((maxpool2_kernel<T_, V_, false>), dim3(g), dim3(256), 0, (hipStream_t)stream, \
                                         (const T_*)x, ldx, (const T_*)nullptr, 0LL, (T_*)y, ldy, N, D, H, W, C, 0)
@@ -965,6 +970,7 @@ int msseg_maxpool2_bwd(const void* x, long long ldx, const void* dy, long long l
     const int esz = dtype == MSSEG_F32 ? 4 : 2;
     const bool vec = vec_ok(x, ldx, C, esz) && vec_ok(dy, lddy, C, esz) && vec_ok(dx, lddx, C, esz);
     const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * ceil_div(C, vec ? 16 / esz : 1);
+    if (total >= 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "maxpool2_bwd: too many elements");
     const int g = grid_for(total, 1);
 #define MP_B(T_, V_) hipLaunchKernelGGL((maxpool2_kernel<T_, V_, true>), dim3(g), dim3(256), 0, (hipStream_t)stream, \
                                         (const T_*)x, ldx, (const T_*)dy, lddy, (T_*)dx, lddx, N, D, H, W, C, accumulate)

@@ -383,20 +383,21 @@ struct ReduceParams {
 // fixed order (deterministic), one thread per output writes the torch-layout gradient.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceParams p) {
     __shared__ float part[8][33];
-    const long long total = (long long)p.M * p.T * p.K;
+    const unsigned total = (unsigned)p.M * (unsigned)p.T * (unsigned)p.K;   // < 2^31 (checked by the host)
+    const unsigned K = (unsigned)p.K, T = (unsigned)p.T, cbw = (unsigned)p.cbw, KT = K * T;
     const int ol = threadIdx.x & 31, sg = threadIdx.x >> 5;
     const long long slabf = (long long)p.T * p.cbw * p.cbw;
-    for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
-        const long long i = base + ol;
+    for (unsigned base = blockIdx.x * 32u; base < total; base += gridDim.x * 32u) {
+        const unsigned i = base + ol;
         float s = 0.f;
-        int k = 0, t = 0, m = 0;
+        unsigned k = 0, t = 0, m = 0;
         if (i < total) {
-            k = (int)(i % p.K);
-            t = (int)((i / p.K) % p.T);
-            m = (int)(i / ((long long)p.K * p.T));
-            const int mb = m / p.cbw, ml = m % p.cbw, kb = k / p.cbw, kl = k % p.cbw;
-            const float* src = p.slabs + ((long long)(mb * p.kblks + kb) * p.nslots) * slabf +
-                               ((long long)t * p.cbw + ml) * p.cbw + kl;
+            m = i / KT;
+            const unsigned rem = i - m * KT;
+            t = rem / K;
+            k = rem - t * K;
+            const unsigned mb = m / cbw, ml = m - mb * cbw, kb = k / cbw, kl = k - kb * cbw;
+            const float* src = p.slabs + ((long long)(mb * (unsigned)p.kblks + kb) * p.nslots) * slabf + (t * cbw + ml) * cbw + kl;
 #pragma unroll 4
             for (int sl = sg; sl < p.nslots; sl += 8) s += src[(long long)sl * slabf];
         }
@@ -406,8 +407,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceParams p)
             float tot = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) tot += part[g][ol];
-            const long long di = (long long)(m / p.M0) * p.s_m1 + (long long)(m % p.M0) * p.s_m0 + (long long)t * p.s_t +
-                                 (long long)(k / p.K0) * p.s_k1 + (long long)(k % p.K0) * p.s_k0;
+            const unsigned m1 = m / (unsigned)p.M0, m0 = m - m1 * (unsigned)p.M0, k1 = k / (unsigned)p.K0, k0 = k - k1 * (unsigned)p.K0;
+            const long long di = (long long)m1 * p.s_m1 + (long long)m0 * p.s_m0 + (long long)t * p.s_t + (long long)k1 * p.s_k1 +
+                                 (long long)k0 * p.s_k0;
             p.dw[di] = p.accumulate ? p.dw[di] + tot : tot;
         }
         __syncthreads();
