@@ -141,6 +141,8 @@ def main():
     if world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MSSEG_BENCH_ONE_DEVICE"):   # rehearsal of the N > 1 control flow on a one-GPU box (with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     hip.load_library()
@@ -158,6 +160,10 @@ def main():
     else:
         net = UNet(1, args.classes, compute_dtype=dtype).to(dev)
     opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=4e-4, betas=(0.9, 0.95), eps=1e-6)
+    if world > 1:   # replicas start from rank 0's weights (as run_training.py does); data stays per-rank
+        from medicalsemseg_amd import layers as _layers
+        torch.distributed.broadcast(opt.flat_param, src=0)
+        _layers.bump_weights_epoch()
     crit = DiceCELoss(smooth_nr=1e-5, smooth_dr=1e-5)
     x, y = synth_batch(args.batch, args.size, args.classes, dev, 13 + rank)
 

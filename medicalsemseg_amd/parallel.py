@@ -36,7 +36,8 @@ def init_from_env(backend: str | None = None):
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # MSSEG_DIST_BACKEND=gloo: rehearse the multi-rank control flow where RCCL cannot run (several ranks on one GPU)
+        backend = os.environ.get("MSSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend=backend, init_method="env://")
