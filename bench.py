@@ -167,13 +167,22 @@ def main():
     crit = DiceCELoss(smooth_nr=1e-5, smooth_dr=1e-5)
     x, y = synth_batch(args.batch, args.size, args.classes, dev, 13 + rank)
 
+    # Data parallel: parallel.GradSync averages the flat gradient buffer over the ranks; with the UNet's two-phase
+    # backward the first (large) all-reduce runs under the tail of the backward.  --split-graph rehearses the same
+    # step structure on one GPU (no collective is issued on a single rank).
+    gsync = parallel.GradSync(opt, net)
+    if args.split_graph and hasattr(net, "defer_backward_tail") and not os.environ.get("MSSEG_NO_GRAD_OVERLAP"):
+        net.defer_backward_tail(True)
+    two_phase = bool(getattr(net, "_defer_tail", False))
+
     def step():
         out = net((x, None, None))
         loss = crit(out, y)
         loss.backward()
-        if world > 1:
-            parallel.all_reduce_flat_grads(opt.flat_grad)
-            opt._gscale.mul_(1.0 / world)
+        if two_phase:
+            gsync.start()
+            net.backward_tail()
+        gsync.finish()
         opt.step()
         opt.zero_grad()
         return loss
@@ -192,6 +201,7 @@ def main():
     # the collective stays outside the graphs, the ~200 kernel launches of the step do not pay Python per launch.
     graph = None
     graph_b = None
+    graph_tail = None
     split = world > 1 or args.split_graph
 
     def part_a():
@@ -200,11 +210,6 @@ def main():
         loss.backward()
         return loss
 
-    def part_mid():
-        if world > 1:
-            parallel.all_reduce_flat_grads(opt.flat_grad)
-            opt._gscale.mul_(1.0 / world)
-
     def part_b():
         opt.step()
         opt.zero_grad()
@@ -212,7 +217,10 @@ def main():
     def replay():
         graph.replay()
         if graph_b is not None:
-            part_mid()
+            if graph_tail is not None:
+                gsync.start()
+                graph_tail.replay()
+            gsync.finish()
             graph_b.replay()
 
     if not args.no_graph:
@@ -232,7 +240,12 @@ def main():
             else:
                 with torch.cuda.graph(graph):
                     static_loss = part_a()
-                part_mid()
+                if two_phase:
+                    gsync.start()
+                    graph_tail = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_tail, pool=graph.pool()):
+                        net.backward_tail()
+                gsync.finish()
                 graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_b):
                     part_b()
@@ -241,7 +254,7 @@ def main():
             sync()
         except Exception as e:  # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-            graph = graph_b = None
+            graph = graph_b = graph_tail = None
             torch.cuda.synchronize()
     t0 = time.perf_counter()
     if graph is not None:
@@ -278,7 +291,9 @@ def main():
         "value": round(value, 3), "unit": "vol/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "launch": ("hipGraph replay" if graph_b is None else "hipGraph replay (fwd+bwd | all-reduce | optimiser)")
+        "launch": ("hipGraph replay" if graph_b is None else
+                   "hipGraph replay (fwd+bwd head | all-reduce under bwd tail | all-reduce | optimiser)" if graph_tail is not None
+                   else "hipGraph replay (fwd+bwd | all-reduce | optimiser)")
                   if graph is not None else "eager",
         "config": {"workload": f"UNet base (MONAI BasicUNet 32-32-64-128-256-32) 1->{args.classes}cls, {args.size}^3 "
                                f"patches, DiceCE + AdamW, per-GPU batch {args.batch}", "global_batch": args.batch * world,

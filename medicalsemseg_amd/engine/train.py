@@ -36,7 +36,8 @@ class _GraphedFwdBwd:
     A UNet step is ~200 kernel launches of 5-150 us; issued from Python they cost ~8 ms of host time per step against
     ~5 ms of GPU time.  Models that declare `graph_safe` (static shapes, no host synchronisation inside the step) and
     ignore (crop_loc, affine) take this path; the optimiser step, gradient clipping, the data-parallel all-reduce and
-    the metrics stay outside the graph, exactly where the reference loop has them."""
+    the metrics stay outside the graph, exactly where the reference loop has them.  With a two-phase backward
+    (parallel.GradSync) the step is two graphs and the first all-reduce starts between them."""
 
     _cache = {}
 
@@ -55,8 +56,12 @@ class _GraphedFwdBwd:
         self.x, self.y = inputs.clone(), labels.clone()
         side = torch.cuda.Stream(device=inputs.device)
         side.wait_stream(torch.cuda.current_stream())
+        net = getattr(model, "module", model)
+        tail = getattr(net, "backward_tail", None) if getattr(net, "_defer_tail", False) else None
         with torch.cuda.stream(side):   # builds the packed-weight images, workspaces and gradient views
             criterion(model((self.x, None, None)), self.y).backward()
+            if tail is not None:
+                tail()
         torch.cuda.current_stream().wait_stream(side)
         optimizer.zero_grad()           # the warm-up pass must not count
         layers.PACK_REGISTRY.prepare()
@@ -66,11 +71,22 @@ class _GraphedFwdBwd:
             self.out = model((self.x, None, None))
             self.loss = criterion(self.out, self.y)
             self.loss.backward()
+        # two-phase backward (parallel.GradSync): the tail of the backward is its own graph, so the all-reduce of the
+        # gradients the head finished can be started between the two replays
+        self.graph_tail = None
+        if tail is not None:
+            self.graph_tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_tail, pool=self.graph.pool()):
+                tail()
 
-    def __call__(self, inputs, labels):
+    def __call__(self, inputs, labels, between=None):
         self.x.copy_(inputs)
         self.y.copy_(labels)
         self.graph.replay()
+        if self.graph_tail is not None:
+            if between is not None:
+                between()
+            self.graph_tail.replay()
         return self.out, self.loss
 
 
@@ -103,8 +119,11 @@ def train_one_epoch(model, data_loader, optimizer, criterion, device, epoch, los
                 crop_loc = misc.get_rel_crop_loc(t)
 
         graphed = _graph_ok(model, criterion, optimizer, loss_scaler, inputs, cfg)
+        gsync = getattr(optimizer, "grad_sync", None)          # parallel.GradSync (data parallel), else None
+        net = getattr(model, "module", model)
         if graphed:
-            outputs, loss = _GraphedFwdBwd.get(model, criterion, optimizer, inputs, labels)(inputs, labels)
+            outputs, loss = _GraphedFwdBwd.get(model, criterion, optimizer, inputs, labels)(
+                inputs, labels, gsync.start if gsync is not None else None)
         else:
             outputs = model((inputs, crop_loc, aff_xyz))   # compute dtype is a property of the model (bf16 / fp32)
             loss = criterion(outputs, labels)
@@ -115,15 +134,18 @@ def train_one_epoch(model, data_loader, optimizer, criterion, device, epoch, los
 
         if not graphed:
             loss_scaler.scale(loss).backward()
+            if getattr(net, "_defer_tail", False):
+                if gsync is not None:
+                    gsync.start()
+                net.backward_tail()
+        if gsync is not None:
+            gsync.finish()   # gradients are averaged over the ranks before clipping, as under DDP
         if cfg.gradient_clipping is not None:
             loss_scaler.unscale_(optimizer)
             if hasattr(optimizer, "clip_grad_norm_"):
                 optimizer.clip_grad_norm_(cfg.gradient_clipping)
             else:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.gradient_clipping)
-        sync = getattr(optimizer, "sync_gradients", None)
-        if sync is not None:
-            sync()   # flat-buffer all-reduce (data parallel)
         loss_scaler.step(optimizer)
         loss_scaler.update()
         optimizer.zero_grad()

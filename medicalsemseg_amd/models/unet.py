@@ -97,6 +97,27 @@ class UNet(nn.Module):
         self.final_conv = nn.Conv3d(f[5], out_channels, kernel_size=1)
         self._build_ops()
 
+    # ---- two-phase backward (data-parallel overlap) ----
+    # With `defer_backward_tail(True)` the autograd backward stops after the decoder and the bottom encoder level
+    # (86 % of the weights, about 2/3 of the backward time) and `backward_tail()` runs encoder levels 3..0.  The caller
+    # starts the all-reduce of the finished gradients in between (parallel.GradSync), which is what DDP's bucketed
+    # overlap does for the reference (/root/reference/run_training.py:82-85).
+    def defer_backward_tail(self, on: bool = True):
+        self._defer_tail = bool(on)
+        self._pending_tail = None
+        return self
+
+    def tail_parameters(self):
+        """parameters whose gradients `backward_tail()` produces"""
+        mods = (self.conv_0, self.down_1, self.down_2, self.down_3)
+        return [p for m in mods for p in m.parameters()]
+
+    def backward_tail(self):
+        pend, self._pending_tail = getattr(self, "_pending_tail", None), None
+        if pend is not None:
+            with torch.no_grad():
+                _UNetFn._run_tail(self, *pend)
+
     def _build_ops(self):
         s = self.slope
         self._enc = [(_cna(self.conv_0.conv_0, s), _cna(self.conv_0.conv_1, s))]
@@ -220,7 +241,28 @@ class _UNetFn(torch.autograd.Function):
             below = unit_norm(net._dec[j - 1][2], saved["dec"][j - 1][2]) if j > 0 else unit_norm(net._enc[4][1], saved["enc"][4][1])
             g, red_c1 = pair(up.bwd(up_in, dcat[..., f[lvl]:], True, next_norm=below))
         # encoder, bottom-up
-        for lvl in range(4, -1, -1):
+        g = _UNetFn._encoder_bwd(net, saved, g, red_c1, skip_grads, (4,))
+        if getattr(net, "_defer_tail", False):
+            net._pending_tail = (saved, g, skip_grads)     # levels 3..0 run in net.backward_tail()
+        else:
+            _UNetFn._encoder_bwd(net, saved, g, None, skip_grads, (3, 2, 1, 0))
+        ctx.saved = None
+        return (None,) * n_in
+
+    @staticmethod
+    def _run_tail(net, saved, g, skip_grads):
+        side = layers.WGRAD_SIDE
+        side.begin(g.device)
+        try:
+            side.set_mode(side.SIDE)
+            _UNetFn._encoder_bwd(net, saved, g, None, skip_grads, (3, 2, 1, 0))
+        finally:
+            side.join()
+
+    @staticmethod
+    def _encoder_bwd(net, saved, g, red_c1, skip_grads, levels):
+        side = layers.WGRAD_SIDE
+        for lvl in levels:
             c0, c1 = net._enc[lvl]
             s0, s1 = saved["enc"][lvl]
             if lvl == 1:
@@ -232,5 +274,4 @@ class _UNetFn(torch.autograd.Function):
                 g = skip_grads[lvl]
             g, red = c1.bwd(s1, g, True, red=(red_c1 if lvl == 4 else None), next_saved=s0, next_cna=c0)
             g = c0.bwd(s0, g, need_dx=(lvl > 0), red=red)
-        ctx.saved = None
-        return (None,) * n_in
+        return g

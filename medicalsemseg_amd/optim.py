@@ -95,9 +95,20 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
         """torch.nn.utils.clip_grad_norm_ semantics, folded into the step as a gradient scale (no extra pass)."""
-        total = self.grad_norm()
-        self._gscale.copy_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+        total = self.grad_norm() * self._gscale   # norm of the gradient the step will apply (after 1/world averaging)
+        self._gscale.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
         return total
+
+    def early_suffix_offset(self, late_params) -> int:
+        """Smallest offset o such that flat_grad[o:] holds no gradient of `late_params` (the ones a split backward
+        produces last): flat_grad[o:] can be all-reduced while those are still being computed."""
+        late = {id(p) for p in late_params}
+        off, o = 0, 0
+        for p, _ in self._views:
+            off += p.numel()
+            if id(p) in late:
+                o = off
+        return o
 
     def state_dict(self):
         return {"flat": True, "step": self._step, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),

@@ -50,6 +50,53 @@ def all_reduce_flat_grads(flat_grad: torch.Tensor, async_op: bool = False):
     return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
+class GradSync:
+    """Gradient averaging over the data-parallel ranks for a FlatAdamW buffer.
+
+    The reference wraps the model in DistributedDataParallel (/root/reference/run_training.py:82-85), whose bucketed
+    all-reduce overlaps the backward pass.  Here the gradients live in one flat fp32 buffer; a model with a two-phase
+    backward (`defer_backward_tail` / `backward_tail` / `tail_parameters`, models/unet.py) lets the buffer go out in two
+    pieces: `start()` after the head of the backward sends everything the head finished (the suffix of the buffer
+    that holds no tail gradient), the tail of the backward runs under that collective, `finish()` sends the rest and
+    folds 1/world into the optimiser's gradient scale.  Models without a split backward get one all-reduce in
+    `finish()`.  No collective is issued on a single rank."""
+
+    def __init__(self, optimizer, model=None):
+        import os
+        self.opt = optimizer
+        self.ws = world_size()
+        self.split = 0
+        self.net = None
+        self._work = []
+        net = getattr(model, "module", model)
+        if (self.ws > 1 and net is not None and hasattr(net, "backward_tail")
+                and not os.environ.get("MSSEG_NO_GRAD_OVERLAP")):
+            o = optimizer.early_suffix_offset(net.tail_parameters())
+            if 0 < o < optimizer.flat_grad.numel():
+                self.split, self.net = o, net
+                net.defer_backward_tail(True)
+
+    @property
+    def overlapped(self) -> bool:
+        return self.net is not None
+
+    def start(self):
+        """after the head of the backward: all-reduce the finished suffix asynchronously"""
+        if self.overlapped:
+            self._work.append(dist.all_reduce(self.opt.flat_grad[self.split:], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        """after the whole backward: all-reduce what is left, wait, and fold the 1/world average into the step"""
+        if self.ws == 1:
+            return
+        g = self.opt.flat_grad
+        self._work.append(dist.all_reduce(g[:self.split] if self.overlapped else g, op=dist.ReduceOp.SUM, async_op=True))
+        for w in self._work:
+            w.wait()
+        self._work = []
+        self.opt._gscale.mul_(1.0 / self.ws)
+
+
 def all_reduce_mean(x: float) -> float:
     """/root/reference/utils/misc.py:307-315"""
     if world_size() == 1:

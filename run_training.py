@@ -53,12 +53,8 @@ def main(cfg):
     groups = add_weight_decay(model, cfg.weight_decay)
     optimizer = FlatAdamW(groups, lr=cfg.lr, betas=(0.9, 0.95), eps=1e-6)
     if cfg.distributed:
-        ws = parallel.world_size()
-
-        def sync_gradients():
-            parallel.all_reduce_flat_grads(optimizer.flat_grad)
-            optimizer._gscale.mul_(1.0 / ws)
-        optimizer.sync_gradients = sync_gradients
+        # gradient averaging over the ranks, overlapped with the tail of the backward where the model splits it
+        optimizer.grad_sync = parallel.GradSync(optimizer, model)
         # identical initial weights on every rank
         torch.distributed.broadcast(optimizer.flat_param, src=0)
     loss_scaler = torch.amp.GradScaler("cuda", enabled=False)

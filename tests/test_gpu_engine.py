@@ -97,6 +97,42 @@ def test_train_epoch_graph_replay_equals_eager(monkeypatch):
     assert float((pa - pb).abs().mean()) < 2e-4 and float((pa - pb).abs().max()) < 2e-3 * 8
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_phase_backward_equals_single_phase(dtype):
+    """defer_backward_tail: head (decoder + bottom level) in autograd's backward, encoder levels 3..0 in backward_tail();
+    the gradients are those of the one-phase backward bit for bit, and the flat-buffer suffix the head finishes is
+    complete before the tail runs (that suffix is what parallel.GradSync all-reduces under the tail)."""
+    from medicalsemseg_amd.models.unet import UNET_FEATURES, UNet
+    from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay
+    torch.manual_seed(3)
+    net = UNet(1, 3, UNET_FEATURES["UNetSmall"], compute_dtype=dtype).to(DEV)
+    opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=1e-3)
+    x = torch.randn(2, 1, 32, 32, 32, device=DEV)
+    dy = torch.randn(2, 3, 32, 32, 32, device=DEV)
+    net((x, None, None)).backward(dy)
+    ref = opt.flat_grad.clone()
+    opt.zero_grad()
+
+    net.defer_backward_tail(True)
+    o = opt.early_suffix_offset(net.tail_parameters())
+    assert 0 < o < opt.flat_grad.numel()
+    net((x, None, None)).backward(dy)
+    head = opt.flat_grad.clone()
+    assert torch.equal(head[o:], ref[o:])                       # everything behind the split is final
+    tail_ids = {id(p) for p in net.tail_parameters()}
+    for p, gv in opt._views:                                    # nothing of the tail has been written yet
+        if id(p) in tail_ids:
+            assert float(gv.abs().max()) == 0.0
+    net.backward_tail()
+    assert torch.equal(opt.flat_grad, ref)
+    net.backward_tail()                                         # idempotent: nothing pending
+    assert torch.equal(opt.flat_grad, ref)
+    net.defer_backward_tail(False)
+    opt.zero_grad()
+    net((x, None, None)).backward(dy)
+    assert torch.equal(opt.flat_grad, ref)
+
+
 def test_run_training_driver_synthetic(tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, "run_training.py"), "--synthetic", "--model", "UNetSmall", "--output_dim", "2",
            "--vol_size", "32", "--n_images_per_batch", "2", "--synthetic_steps", "3", "--epochs", "2", "--val_interval", "2",

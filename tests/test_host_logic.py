@@ -152,7 +152,36 @@ def _gloo_worker(rank, world, port, q):
     m = misc.SmoothedValue()
     m.update(float(rank + 1), n=rank + 1)
     m.synchronize_between_processes()
-    q.put((rank, float(flat[0]), parallel.all_reduce_mean(float(rank)), (lo, hi), m.count, m.total))
+    # GradSync with a two-phase backward: the suffix goes out in start(), the rest in finish(); stub optimiser / model
+    # objects stand in for FlatAdamW / UNet (both GPU-only), the protocol is what is under test
+    class _Opt:
+        flat_grad = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        _gscale = torch.ones(1)
+
+        @staticmethod
+        def early_suffix_offset(late):
+            return 300
+
+    class _Net:
+        deferred = False
+
+        def defer_backward_tail(self, on=True):
+            self.deferred = on
+
+        def tail_parameters(self):
+            return []
+
+        def backward_tail(self):
+            pass
+
+    net = _Net()
+    gs = parallel.GradSync(_Opt, net)
+    gs.start()
+    after_start = (_Opt.flat_grad[299].item(), _Opt.flat_grad[300].item())   # head untouched so far
+    gs.finish()
+    gsync = (gs.overlapped, net.deferred, gs.split, after_start[0], float(_Opt.flat_grad[299]), float(_Opt.flat_grad[999]),
+             float(_Opt._gscale))
+    q.put((rank, float(flat[0]), parallel.all_reduce_mean(float(rank)), (lo, hi), m.count, m.total, gsync))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -172,6 +201,11 @@ def test_gloo_world_size_2_flat_allreduce_and_window_sharding():
     assert [r[2] for r in res] == [0.5, 0.5]            # mean of ranks
     assert res[0][3] == (0, 500) and res[1][3] == (500, 1000)
     assert all(r[4] == 3 and r[5] == 5.0 for r in res)  # meter: counts 1+2, totals 1*1 + 2*2
+    for r in res:
+        ov, deferred, split, head_before, head_after, tail_after, gscale = r[6]
+        assert ov and deferred and split == 300
+        assert head_before == 299.0 * (r[0] + 1)         # start() reduces only flat_grad[300:]
+        assert head_after == 299.0 * 3 and tail_after == 999.0 * 3 and gscale == 0.5
 
 
 def test_window_sharding_is_a_partition():
