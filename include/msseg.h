@@ -218,6 +218,14 @@ int msseg_window_attention_fwd(const void* qkv, const float* qkv_bias, const flo
 int msseg_window_attention_bwd(const void* qkv, const float* qkv_bias, const float* table, const void* out,
                                const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
                                int C, int heads, int ws, int shift, int dtype, msseg_stream_t stream);
+/* Same with a caller workspace (bytes from msseg_window_attention_bwd_workspace_bytes; 0 = this shape/dtype has no use
+ * for one).  With it the bias-table gradient (swin_nnformer.py:147-155 in reverse) is computed without atomics: dS tiles
+ * in bf16 -> sum over windows -> gather per table entry, deterministic.  workspace == NULL behaves as the call above. */
+size_t msseg_window_attention_bwd_workspace_bytes(int B, int S, int H, int W, int C, int heads, int ws, int shift, int dtype);
+int msseg_window_attention_bwd_ws(const void* qkv, const float* qkv_bias, const float* table, const void* out,
+                                  const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
+                                  int C, int heads, int ws, int shift, int dtype, void* workspace, size_t workspace_bytes,
+                                  msseg_stream_t stream);
 /* LayerNorm over the channel dim of rows x C (nn.LayerNorm, eps 1e-5); mean/rstd [rows] saved for backward. */
 int msseg_layernorm_fwd(const void* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
                         float* mean, float* rstd, long long rows, int C, float eps, int dtype, msseg_stream_t stream);

@@ -513,17 +513,36 @@ int msseg_window_attention_fwd(const void* qkv, const float* qkv_bias, const flo
     return MSSEG_OK;
 }
 
-int msseg_window_attention_bwd(const void* qkv, const float* qkv_bias, const float* table, const void* out,
-                               const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
-                               int C, int heads, int ws, int shift, int dtype, msseg_stream_t stream) {
+static bool attn_bwd_on_mfma(const AttnParams& p, int C, int dtype) {
+    return dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 224 && p.M3 <= 2047 && (C % 8) == 0 &&
+           !getenv("MSSEG_ATTN_NO_MFMA") && !getenv("MSSEG_ATTN_BWD_NO_MFMA");
+}
+
+size_t msseg_window_attention_bwd_workspace_bytes(int B, int S, int H, int W, int C, int heads, int ws, int shift, int dtype) {
+    AttnParams p{};
+    if (fill_attn(p, B, S, H, W, C, heads, ws, shift) != MSSEG_OK) return 0;
+    if (!attn_bwd_on_mfma(p, C, dtype) || getenv("MSSEG_ATTN_BWD_NO_WS")) return 0;
+    return msseg_window_attention_bwd_mfma_ws_bytes(p);
+}
+
+int msseg_window_attention_bwd_ws(const void* qkv, const float* qkv_bias, const float* table, const void* out,
+                                  const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
+                                  int C, int heads, int ws, int shift, int dtype, void* workspace, size_t workspace_bytes,
+                                  msseg_stream_t stream) {
     if (!qkv || !table || !out || !lse || !dout || !dqkv) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd: null pointer");
     AttnParams p{};
     if (int rc = fill_attn(p, B, S, H, W, C, heads, ws, shift)) return rc;
     p.qkv = qkv; p.qkv_bias = qkv_bias; p.table = table; p.out = (void*)out; p.lse = (float*)lse; p.dout = dout;
     p.dqkv = dqkv; p.dtable = dtable;
-    if (dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 224 && (C % 8) == 0 && !getenv("MSSEG_ATTN_NO_MFMA") &&
-        !getenv("MSSEG_ATTN_BWD_NO_MFMA")) {
-        // bf16: all five contractions of the backward on the matrix cores (attention_mfma.hip)
+    if (attn_bwd_on_mfma(p, C, dtype)) {
+        // bf16: all five contractions of the backward on the matrix cores (attention_mfma.hip); with a workspace the
+        // table gradient is a window sum + gather instead of LDS float atomics
+        if (workspace != nullptr && dtable != nullptr) {
+            if (workspace_bytes < msseg_window_attention_bwd_mfma_ws_bytes(p))
+                MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                           msseg_window_attention_bwd_mfma_ws_bytes(p));
+            msseg_window_attention_bwd_mfma_carve(p, workspace);
+        }
         return msseg_window_attention_bwd_mfma(p, (hipStream_t)stream);
     }
     const size_t base = (size_t)p.N * p.hd * 4 * 4 + (size_t)p.N * 5 * 4 + (size_t)p.M3 * 4;
@@ -535,6 +554,13 @@ int msseg_window_attention_bwd(const void* qkv, const float* qkv_bias, const flo
     else MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd: bad dtype");
     MSSEG_CHECK_LAUNCH("window_attention_bwd");
     return MSSEG_OK;
+}
+
+int msseg_window_attention_bwd(const void* qkv, const float* qkv_bias, const float* table, const void* out,
+                               const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
+                               int C, int heads, int ws, int shift, int dtype, msseg_stream_t stream) {
+    return msseg_window_attention_bwd_ws(qkv, qkv_bias, table, out, lse, dout, dqkv, dtable, B, S, H, W, C, heads, ws, shift,
+                                         dtype, nullptr, 0, stream);
 }
 
 int msseg_layernorm_fwd(const void* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,

@@ -14,6 +14,11 @@ struct AttnParams {
     void* dqkv;           // backward: [B,S,H,W,3C]
     float* dtable;        // backward: [(2ws-1)^3][heads] fp32, accumulated (atomics from per-workgroup LDS sums)
     int dtab_all_heads;   // the workgroup keeps dtable partial sums for all heads in LDS across its windows
+    // MFMA backward with a caller workspace: dS of every (window, head) is written in bf16 MFMA-fragment order, summed
+    // over the windows in `ds_groups` groups, and the table gradient is gathered from the sums (no atomics)
+    void* ds_ws;          // bf16 [nwin_total][heads][NKT*NKT][64 lanes][16]
+    float* ds_psum;       // fp32 [ds_groups][heads][NKT*NKT][64][16]
+    int ds_groups;
     int B, S, H, W, C, heads, hd, ws, shift;
     int Sp, Hp, Wp, nWs, nWh, nWw, N, M3, nwin_total;
     float scale;
@@ -43,3 +48,6 @@ MSSEG_DEVFN int window_token(const AttnParams& p, int wz, int wy, int wx, int po
 
 int msseg_window_attention_fwd_mfma(const msseg_attn::AttnParams& p, hipStream_t stream);  // attention_mfma.hip
 int msseg_window_attention_bwd_mfma(const msseg_attn::AttnParams& p, hipStream_t stream);
+// bytes of workspace the MFMA backward wants for its atomics-free table gradient; carve() points p.ds_* into it
+size_t msseg_window_attention_bwd_mfma_ws_bytes(const msseg_attn::AttnParams& p);
+void msseg_window_attention_bwd_mfma_carve(msseg_attn::AttnParams& p, void* workspace);

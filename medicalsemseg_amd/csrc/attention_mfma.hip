@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const AttnParams
 // Scores are recomputed in each pass (2 + 2 MFMAs per tile pair at head dim 16) instead of transposing a 32 x 32
 // accumulator through LDS.  Semantics (padded tokens carry the qkv bias, padded queries get no gradient, padded rows
 // of the MFMA tiles are masked) follow win_attn_bwd_kernel in attention.hip.
-template <int HD, int NKT>
+template <int HD, int NKT, bool DSWS>
 __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams p) {
     constexpr int NP = NKT * 32;
     constexpr int KS = HD / 16;
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
         for (int h = 0; h < p.heads; ++h) {
             __syncthreads();
             for (int i = tid; i < p.M3; i += 256) { tabS[i] = p.table[(long long)i * p.heads + h]; dtabS[i] = 0.f; }
+            bf16_t* dsw = DSWS ? (bf16_t*)p.ds_ws + ((long long)wb * p.heads + h) * (NKT * NKT * 1024) + lane * 16 : nullptr;
             constexpr int CPT = HD / 8;
             for (int i = tid; i < NP * CPT * 4; i += 256) {   // q, k, v, dO
                 const int which = i / (NP * CPT), rem = i % (NP * CPT);
@@ -301,13 +302,15 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
                         const int key = j * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
                         const unsigned short ki = kinfo[key];
                         float ds = 0.f;
-                        if (ki != 0xFFFF && qinfo != 0xFFFF) {
+                        // (a padded query's dQ row is never written, so with DSWS its dS may be zeroed here: the stored
+                        // tile then holds exactly the table-gradient contributions)
+                        if (ki != 0xFFFF && qinfo != 0xFFFF && (!DSWS || qlive)) {
                             const int ti = qcode - (ki & 2047);
                             float sc = X[g] * p.scale + tabS[ti];
                             if (p.use_mask && (ki >> 11) != qreg) sc += -100.f;
                             const float pr = __expf(sc - lq);
                             ds = pr * (DP[g] - dq_del);
-                            if (p.dtable && qlive) atomicAdd(&dtabS[ti], ds);
+                            if (!DSWS && p.dtable && qlive) atomicAdd(&dtabS[ti], ds);
                         }
                         X[g] = ds;
                     }
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
                         bf16x8_t df;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) df[e] = (bf16_t)X[8 * s + e];
+                        if (DSWS) *(bf16x8_t*)(dsw + (qt * NKT + j) * 1024 + 8 * s) = df;   // 2 KB per wave and tile pair
                         const bf16_t* kp = kT + vrow * NP + j * 32 + 16 * s + 4 * hh;
                         const bf16x4_t k0 = *(const bf16x4_t*)kp;
                         const bf16x4_t k1 = *(const bf16x4_t*)(kp + 8);
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
                     }
                 }
             }
-            if (p.dtable) {
+            if (!DSWS && p.dtable) {
                 __syncthreads();
                 for (int i = tid; i < p.M3; i += 256) {
                     const float v = dtabS[i];
@@ -415,20 +419,100 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
     }
 }
 
+// ---- table gradient without atomics (DSWS) ----
+// step 1: sum the bf16 dS tiles over the windows of one group; element order is the MFMA fragment order the backward
+// kernel wrote, identical for every window, so this is a plain strided sum (16 B per thread and window)
+__global__ __launch_bounds__(256) void attn_ds_window_sum_kernel(const bf16_t* __restrict__ ws, float* __restrict__ psum,
+                                                                 int nwin, int heads, int E, int chunk) {
+    const int e8 = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y, g = blockIdx.z;
+    if (e8 * 8 >= E) return;
+    const int w0 = g * chunk, w1 = min(nwin, w0 + chunk);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const long long stride = (long long)heads * E;
+    const bf16_t* src = ws + ((long long)w0 * heads + h) * E + e8 * 8;
+    int w = w0;
+    for (; w + 4 <= w1; w += 4) {
+        bf16x8_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8_t*)(src + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
+        src += 4 * stride;
+    }
+    for (; w < w1; ++w) {
+        const bf16x8_t v = *(const bf16x8_t*)src;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        src += stride;
+    }
+    float* dst = psum + ((long long)g * heads + h) * E + e8 * 8;
+    *(float4*)dst = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *(float4*)(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+// step 2: one workgroup per (table entry, head).  The entry's relative offset (dz, dy, dx) fixes the key of every query:
+// thread i reads the summed dS of (query i, key i - offset) from each group and the block adds them up in a fixed order.
+__global__ __launch_bounds__(256) void attn_dtable_gather_kernel(const float* __restrict__ psum, float* __restrict__ dtable,
+                                                                 int groups, int heads, int nkt, int wsz, int N) {
+    __shared__ float red[256];
+    const int ti = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
+    const int m = 2 * wsz - 1;
+    const int dz = ti / (m * m) - (wsz - 1), dy = (ti / m) % m - (wsz - 1), dx = ti % m - (wsz - 1);
+    float v = 0.f;
+    if (i < N) {
+        const int jz = i / (wsz * wsz) - dz, jy = (i / wsz) % wsz - dy, jx = i % wsz - dx;
+        if (jz >= 0 && jz < wsz && jy >= 0 && jy < wsz && jx >= 0 && jx < wsz) {
+            const int j = (jz * wsz + jy) * wsz + jx;
+            // fragment order of the backward kernel's pass 1: tile (i / 32, j / 32), lane = (i % 32) + 32 * hh,
+            // register g with key offset (g & 3) + 8 * (g >> 2) + 4 * hh
+            const int kk = j & 31, hh = (kk >> 2) & 1, g = (kk & 3) + 4 * (kk >> 3);
+            const long long e = ((long long)((i >> 5) * nkt + (j >> 5)) * 64 + (i & 31) + 32 * hh) * 16 + g;
+            const long long E = (long long)nkt * nkt * 1024;
+            for (int q = 0; q < groups; ++q) v += psum[((long long)q * heads + h) * E + e];
+        }
+    }
+    red[i] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (i < s) red[i] += red[i + s];
+        __syncthreads();
+    }
+    if (i == 0) dtable[(long long)ti * heads + h] += red[0];
+}
+
+constexpr int DS_GROUPS = 8;
+
 template <int HD, int NKT> int launch_bwd(const AttnParams& p, hipStream_t stream) {
     constexpr int NP = NKT * 32;
     const size_t smem = (size_t)7 * NP * HD * 2 + (size_t)2 * NP * 4 + (size_t)2 * p.M3 * 4 + (size_t)NP * 4 + (size_t)NP * 2 + 16;
-    auto kern = win_attn_bwd_mfma_kernel<HD, NKT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    const bool dsws = p.ds_ws != nullptr && p.dtable != nullptr;
+    auto kern = dsws ? win_attn_bwd_mfma_kernel<HD, NKT, true> : win_attn_bwd_mfma_kernel<HD, NKT, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[dsws]) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             MSSEG_FAIL(MSSEG_ELAUNCH, "window_attention_bwd_mfma: cannot set dynamic LDS size");
-        attr_set = true;
+        attr_set[dsws] = true;
     }
     if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd_mfma: window too large for LDS (%zu bytes)", smem);
     int gx = p.nwin_total < msseg_num_cus() * 2 ? p.nwin_total : msseg_num_cus() * 2;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), smem, stream, p);
     MSSEG_CHECK_LAUNCH("window_attention_bwd_mfma");
+    if (dsws) {
+        const int E = NKT * NKT * 1024;
+        const int groups = p.ds_groups;
+        const int chunk = (p.nwin_total + groups - 1) / groups;
+        hipLaunchKernelGGL(attn_ds_window_sum_kernel, dim3((E / 8 + 255) / 256, p.heads, groups), dim3(256), 0, stream,
+                           (const bf16_t*)p.ds_ws, p.ds_psum, p.nwin_total, p.heads, E, chunk);
+        MSSEG_CHECK_LAUNCH("attn_ds_window_sum");
+        hipLaunchKernelGGL(attn_dtable_gather_kernel, dim3(p.M3, p.heads), dim3(256), 0, stream, (const float*)p.ds_psum,
+                           p.dtable, groups, p.heads, NKT, p.ws, p.N);
+        MSSEG_CHECK_LAUNCH("attn_dtable_gather");
+    }
     return MSSEG_OK;
 }
 
@@ -458,6 +542,25 @@ template <int HD> int launch_hd(const AttnParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+static int bwd_nkt(const AttnParams& p) {   // the NKT instantiation launch_bwd_hd picks
+    const int nkt = (p.N + 31) / 32;
+    return nkt == 1 ? 1 : (nkt == 2 ? 2 : (nkt <= 4 ? 4 : 7));
+}
+
+static int ds_groups_for(const AttnParams& p) { return p.nwin_total < DS_GROUPS ? p.nwin_total : DS_GROUPS; }
+
+size_t msseg_window_attention_bwd_mfma_ws_bytes(const AttnParams& p) {
+    const size_t E = (size_t)bwd_nkt(p) * bwd_nkt(p) * 1024;
+    return (size_t)p.nwin_total * p.heads * E * 2 + (size_t)ds_groups_for(p) * p.heads * E * 4;
+}
+
+void msseg_window_attention_bwd_mfma_carve(AttnParams& p, void* workspace) {
+    const size_t E = (size_t)bwd_nkt(p) * bwd_nkt(p) * 1024;
+    p.ds_ws = workspace;
+    p.ds_psum = (float*)((char*)workspace + (size_t)p.nwin_total * p.heads * E * 2);
+    p.ds_groups = ds_groups_for(p);
+}
 
 int msseg_window_attention_bwd_mfma(const AttnParams& p, hipStream_t stream) {
     if (p.M3 > 2047 || p.N > 224) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd_mfma: window too large");

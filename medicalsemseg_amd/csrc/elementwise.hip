@@ -854,8 +854,12 @@ int msseg_pack_weights(const float* src, void* dst, int dtype, int M, int M0, in
 int msseg_pack_weights_batch(const msseg_pack_job* jobs_dev, int njobs, long long max_total, int dtype,
                              msseg_stream_t stream) {
     if (!jobs_dev || njobs < 1 || njobs > 65535 || max_total < 1) MSSEG_FAIL(MSSEG_EINVAL, "pack_weights_batch: bad args");
-    long long gx = ceil_div_ll(max_total, 256LL * 8);
-    if (gx > 64) gx = 64;
+    // blocks per job sized by the largest image (16 chunks of 16 B per thread); smaller jobs leave their extra blocks
+    // idle.  The cap keeps the grid of a many-job table small: the 64 MB conv weights of Swin-UNETR's deep stages want
+    // hundreds of blocks, the UNet's largest (7 MB) about fifty.
+    long long gx = ceil_div_ll(max_total, 256LL * 8 * 16);
+    if (gx > 512) gx = 512;
+    if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)njobs);
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev),
                hipLaunchKernelGGL(pack_weights_batch_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev));

@@ -46,6 +46,9 @@ SIGNATURES = {
     "msseg_zero_stuff2": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_window_attention_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_window_attention_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_window_attention_bwd_ws": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
+                                       _sz, _vp], _i),
+    "msseg_window_attention_bwd_workspace_bytes": ([_i, _i, _i, _i, _i, _i, _i, _i, _i], _sz),
     "msseg_layernorm_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _ll, _i, _f, _i, _vp], _i),
     "msseg_layernorm_bwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _vp], _i),
     "msseg_layernorm_param_grad": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _i, _ll, _i, _vp, _sz, _i, _vp], _i),
@@ -689,9 +692,13 @@ def window_attention_bwd(qkv, qkv_bias, table, out, lse, dout, dqkv, dtable, hea
     _need_gpu(qkv, table, out, lse, dout, dqkv)
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
     B, S, H, W, C3 = qkv.shape
-    _ck(lib().msseg_window_attention_bwd(_p(qkv), _p(qkv_bias), _p(table), _p(out), _p(lse), _p(dout), _p(dqkv),
-                                         _p(dtable), B, S, H, W, C3 // 3, heads, ws, shift, dt(qkv), _stream()),
-        "window_attention_bwd")
+    wsb = 0
+    if dtable is not None:
+        wsb = int(lib().msseg_window_attention_bwd_workspace_bytes(B, S, H, W, C3 // 3, heads, ws, shift, dt(qkv)))
+    work = torch.empty(wsb, dtype=torch.uint8, device=qkv.device) if wsb else None
+    _ck(lib().msseg_window_attention_bwd_ws(_p(qkv), _p(qkv_bias), _p(table), _p(out), _p(lse), _p(dout), _p(dqkv),
+                                            _p(dtable), B, S, H, W, C3 // 3, heads, ws, shift, dt(qkv), _p(work), wsb,
+                                            _stream()), "window_attention_bwd")
     return dqkv
 
 

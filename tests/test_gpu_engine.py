@@ -142,3 +142,19 @@ def test_run_training_driver_synthetic(tmp_path):
     assert os.path.exists(tmp_path / "checkpoint-1.pth") and os.path.exists(tmp_path / "log.txt")
     ck = torch.load(tmp_path / "checkpoint-1.pth", map_location="cpu", weights_only=True)
     assert "conv_0.conv_0.conv.weight" in ck["model"] and ck["epoch"] == 1
+
+
+def test_run_training_two_ranks_share_one_gpu_over_gloo(tmp_path):
+    """data-parallel control flow of the driver (weight broadcast, GradSync with the two-phase backward, meter and
+    loss reductions, rank-0 checkpointing) with two gloo ranks on this one GPU; RCCL needs one GPU per rank"""
+    env = dict(os.environ, MSSEG_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "run_training.py"), "--synthetic", "--backend", "gloo",
+           "--model", "UNetSmall", "--output_dim", "2", "--vol_size", "32", "--n_images_per_batch", "2",
+           "--synthetic_steps", "3", "--epochs", "2", "--val_interval", "2", "--synthetic_val_size", "48",
+           "--warmup_epochs", "1", "--gradient_clipping", "1.0", "--output_dir", str(tmp_path), "--save_ckpt_freq", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    ck = torch.load(tmp_path / "checkpoint-1.pth", map_location="cpu", weights_only=True)
+    assert ck["epoch"] == 1 and all(torch.isfinite(v).all() for v in ck["model"].values())

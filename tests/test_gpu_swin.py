@@ -64,6 +64,38 @@ def test_window_attention_vs_reference_golden(golden_dir, dtype, tag, dim, ws, h
             assert _rel(m.qkv.weight.grad, g[f"dqkvw_{mk}"]) < (1e-3 if dtype == torch.float32 else 5e-2)
 
 
+@pytest.mark.parametrize("R,ws,heads,C,shift", [(12, 6, 3, 48, 0), (10, 6, 3, 48, 3), (6, 3, 4, 64, 1)])
+def test_attention_bwd_table_gradient_workspace_path_equals_atomics_path(monkeypatch, R, ws, heads, C, shift):
+    """bf16 MFMA backward: the bias-table gradient from the dS workspace (window sum + gather, deterministic) against the
+    LDS-atomics form of the same kernel; dqkv is the same arithmetic in both (R = 10 pads the volume to 12)."""
+    from medicalsemseg_amd import hip
+    torch.manual_seed(5)
+    qkv = torch.randn(2, R, R, R, 3 * C, device=DEV).bfloat16()
+    qb = torch.randn(3 * C, device=DEV)
+    tab = torch.randn((2 * ws - 1) ** 3, heads, device=DEV) * 0.1
+    out = torch.empty(2, R, R, R, C, device=DEV, dtype=torch.bfloat16)
+    dout = torch.randn_like(out)
+    lse = hip.window_attention_fwd(qkv, qb, tab, out, heads, ws, shift)
+    res = []
+    for no_ws in (False, True):
+        if no_ws:
+            monkeypatch.setenv("MSSEG_ATTN_BWD_NO_WS", "1")
+        else:
+            monkeypatch.delenv("MSSEG_ATTN_BWD_NO_WS", raising=False)
+        dqkv = torch.empty_like(qkv)
+        dtab = torch.full_like(tab, 0.5)          # accumulate semantics: += on both paths
+        hip.window_attention_bwd(qkv, qb, tab, out, lse, dout, dqkv, dtab, heads, ws, shift)
+        res.append((dqkv.float(), dtab.clone()))
+    monkeypatch.delenv("MSSEG_ATTN_BWD_NO_WS", raising=False)
+    assert torch.equal(res[0][0], res[1][0])
+    d = (res[0][1] - res[1][1]).norm() / (res[1][1] - 0.5).norm()
+    assert float(d) < 5e-3                        # dS rounded to bf16 before the sum over windows
+    # deterministic: a second call gives the same bits
+    dtab2 = torch.full_like(tab, 0.5)
+    hip.window_attention_bwd(qkv, qb, tab, out, lse, dout, torch.empty_like(qkv), dtab2, heads, ws, shift)
+    assert torch.equal(dtab2, res[0][1])
+
+
 @pytest.mark.parametrize("shift", [0, 3])
 def test_swin_block_vs_reference_golden(golden_dir, shift):
     from medicalsemseg_amd.models.swin_unetr import _Block
