@@ -172,6 +172,12 @@ int msseg_channel_stats(const void* x, long long ldx, float* stats, int N, long 
 int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
                            const void* residual, long long ldr, void* y, long long ldy, int N, long long S, int C,
                            float eps, float slope, int dtype, msseg_stream_t stream);
+/* The same fused with the MaxPool3d(2) that follows it in an encoder level (MONAI BasicUNet Down = MaxPool3d(2) -> TwoConv):
+ * y as above (no residual) and pooled[n][d/2][h/2][w/2][c] = max over the 2x2x2 cell of y as stored; equals
+ * msseg_maxpool2_fwd(y) bit for bit.  D, H, W even; rows 16-byte aligned, C a multiple of 16 / sizeof(element). */
+int msseg_instnorm_act_pool_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
+                                void* y, long long ldy, void* pooled, long long ldp, int N, int D, int H, int W, int C,
+                                float eps, float slope, int dtype, msseg_stream_t stream);
 /* backward, pass 1: red[n][c] = (sum dz, sum dz*xhat), dz = dy * lrelu'(z): the sign of the pre-activation z is taken
  * from the forward output y, or -- y == NULL, layers without residual -- recomputed as x*rstd*gamma + beta - mean*...,
  * which saves one tensor read (gamma/beta = the forward's affine parameters, nullable);

@@ -526,6 +526,71 @@ __global__ __launch_bounds__(MODE == 1 ? RED_THREADS : 256) void instnorm_kernel
     }
 }
 
+// InstanceNorm + LeakyReLU forward fused with the MaxPool3d(2) that follows it in an encoder level: one thread owns a
+// 2x2x2 cell x one 16-byte channel chunk, writes the eight activated voxels and their maximum.  The maximum is taken
+// over the values as stored (rounded to T), so the pooled tensor equals maxpool2_kernel applied to the stored activation
+// bit for bit (same NaN propagation, and the backward's arg-max recomputation sees the same numbers).
+struct NormPoolParams {
+    const void* x; long long ldx;
+    const float* stats; const float* gamma; const float* beta;
+    void* y; long long ldy;
+    void* pooled; long long ldp;
+    int N, D, H, W, C; float eps, slope;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_pool_fwd_kernel(const NormPoolParams p) {
+    constexpr int WD = DT<T>::EPC;
+    const int OD = p.D / 2, OH = p.H / 2, OW = p.W / 2;
+    const unsigned ug = (unsigned)(p.C / WD);
+    const unsigned total = (unsigned)((long long)p.N * OD * OH * OW * ug);   // < 2^31: checked by the host wrapper
+    const long long S = (long long)p.D * p.H * p.W;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        unsigned t = i / ug;
+        const int g = (int)(i - t * ug);
+        unsigned t2 = t / (unsigned)OW;
+        const int ow = (int)(t - t2 * (unsigned)OW);
+        t = t2 / (unsigned)OH;
+        const int oh = (int)(t2 - t * (unsigned)OH);
+        const int n = (int)(t / (unsigned)OD);
+        const int od = (int)(t - (unsigned)n * (unsigned)OD);
+        float sc[WD], sh[WD], best[WD];
+#pragma unroll
+        for (int e = 0; e < WD; ++e) {
+            const int c = g * WD + e;
+            float mean, rstd;
+            mean_rstd(p.stats, n, p.C, c, S, p.eps, mean, rstd);
+            sc[e] = rstd * (p.gamma ? p.gamma[c] : 1.f);
+            sh[e] = (p.beta ? p.beta[c] : 0.f) - mean * sc[e];
+            best[e] = -INFINITY;
+        }
+        Chunk<T> in[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long vox = (((long long)n * p.D + 2 * od + (k >> 2)) * p.H + 2 * oh + ((k >> 1) & 1)) * p.W + 2 * ow + (k & 1);
+            in[k].load((const T*)p.x + vox * p.ldx + g * WD);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long vox = (((long long)n * p.D + 2 * od + (k >> 2)) * p.H + 2 * oh + ((k >> 1) & 1)) * p.W + 2 * ow + (k & 1);
+            Chunk<T> o;
+#pragma unroll
+            for (int e = 0; e < WD; ++e) {
+                const float z = in[k].v[e] * sc[e] + sh[e];
+                const float a = (float)(T)(z > 0.f ? z : z * p.slope);
+                o.v[e] = a;
+                if (a > best[e] || a != a) best[e] = a;
+            }
+            o.store((T*)p.y + vox * p.ldy + g * WD);
+        }
+        Chunk<T> b;
+#pragma unroll
+        for (int e = 0; e < WD; ++e) b.v[e] = best[e];
+        const long long ovox = (((long long)n * OD + od) * OH + oh) * OW + ow;
+        b.store((T*)p.pooled + ovox * p.ldp + g * WD);
+    }
+}
+
 template <typename T, int MODE> int launch_norm(NormParams& p, int N, bool vec, hipStream_t st) {
     constexpr int NTHR = MODE == 1 ? RED_THREADS : 256;
     const RowMap m = row_map(p.C, vec ? DT<T>::EPC : 1, NTHR);
@@ -914,6 +979,26 @@ int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, con
     const bool vec = vec_ok(x, ldx, C, esz) && vec_ok(y, ldy, C, esz) && (!residual || vec_ok(residual, ldr, C, esz));
     DISPATCH_T(dtype, return (launch_norm<float, 0>(p, N, vec, (hipStream_t)stream)),
                return (launch_norm<bf16_t, 0>(p, N, vec, (hipStream_t)stream)));
+}
+
+int msseg_instnorm_act_pool_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
+                                void* y, long long ldy, void* pooled, long long ldp, int N, int D, int H, int W, int C,
+                                float eps, float slope, int dtype, msseg_stream_t stream) {
+    if (!x || !stats || !y || !pooled || N < 1 || D < 2 || H < 2 || W < 2 || C < 1)
+        MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_pool_fwd: bad args");
+    if ((D | H | W) & 1) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_pool_fwd: odd spatial size %dx%dx%d", D, H, W);
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_pool_fwd: bad dtype");
+    if (!(vec_ok(x, ldx, C, esz) && vec_ok(y, ldy, C, esz) && vec_ok(pooled, ldp, C, esz)))
+        MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_pool_fwd: needs 16-byte aligned rows and a channel count multiple of %d", 16 / esz);
+    const long long total = (long long)N * (D / 2) * (H / 2) * (W / 2) * (C / (16 / esz));
+    if (total >= 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_pool_fwd: too many elements");
+    NormPoolParams p{x, ldx, stats, gamma, beta, y, ldy, pooled, ldp, N, D, H, W, C, eps, slope};
+    const int g = grid_for(total, 1);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_pool_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, p),
+               hipLaunchKernelGGL(instnorm_pool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, p));
+    MSSEG_CHECK_LAUNCH("instnorm_act_pool_fwd");
+    return MSSEG_OK;
 }
 
 int msseg_instnorm_act_bwd_reduce(const void* x, long long ldx, const float* stats, const float* gamma,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "msseg_deconv_k2s2_wgrad": ([_vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_channel_stats": ([_vp, _ll, _vp, _i, _ll, _i, _vp, _sz, _i, _vp], _i),
     "msseg_instnorm_act_fwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
+    "msseg_instnorm_act_pool_fwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _f, _f, _i, _vp], _i),
     "msseg_instnorm_act_bwd_reduce": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _ll, _i, _f, _f, _vp, _sz, _i, _vp], _i),
     "msseg_instnorm_act_bwd_apply": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
     "msseg_maxpool2_fwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -492,6 +493,22 @@ def instnorm_act_fwd(x, stats, gamma, beta, y, slope, eps=1e-5, residual=None):
                                      ld(residual) if residual is not None else 0, _p(y), ld(y), N, S, Cc, eps, slope,
                                      dt(x), _stream()), "instnorm_act_fwd")
     return y
+
+
+def instnorm_pool_ok(x, y, pooled) -> bool:
+    """the fused InstanceNorm + LeakyReLU + MaxPool3d(2) kernel wants even spatial sizes and 16-byte channel chunks"""
+    epc = 16 // x.element_size()
+    return (x.dim() == 5 and all(int(d) % 2 == 0 for d in x.shape[1:4]) and x.shape[-1] % epc == 0
+            and all(ld(t) % epc == 0 and t.data_ptr() % 16 == 0 for t in (x, y, pooled)))
+
+
+def instnorm_act_pool_fwd(x, stats, gamma, beta, y, pooled, slope, eps=1e-5):
+    """y = lrelu(instance_norm(x)) and pooled = max_pool3d(y, 2) in one pass over x (channels-last [N, D, H, W, C])"""
+    _need_gpu(x, stats, y, pooled)
+    N, D, H, W, Cc = x.shape
+    _ck(lib().msseg_instnorm_act_pool_fwd(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(y), ld(y), _p(pooled), ld(pooled),
+                                          N, D, H, W, Cc, eps, slope, dt(x), _stream()), "instnorm_act_pool_fwd")
+    return y, pooled
 
 
 def instnorm_act_bwd(x, stats, gamma, y, dy, dx, slope, eps=1e-5, dres=None, dgamma=None, dbeta=None,

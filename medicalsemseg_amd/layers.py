@@ -393,10 +393,18 @@ class InstNormAct:
                  eps: float = 1e-5):
         self.gamma, self.beta, self.slope, self.eps = gamma, beta, float(slope), float(eps)
 
-    def fwd(self, y_raw, out=None, residual=None, stats=None):
+    def fwd(self, y_raw, out=None, residual=None, stats=None, pooled=None):
+        """pooled: optional [N, D/2, H/2, W/2, C] tensor that receives max_pool3d(result, 2) from the same pass"""
         if stats is None:
             stats = hip.channel_stats(y_raw)
         a = out if out is not None else torch.empty_like(y_raw, memory_format=torch.contiguous_format)
+        if pooled is not None:
+            if residual is None and hip.instnorm_pool_ok(y_raw, a, pooled) and not os.environ.get("MSSEG_NO_NORM_POOL"):
+                hip.instnorm_act_pool_fwd(y_raw, stats, self.gamma, self.beta, a, pooled, self.slope, self.eps)
+                return a, stats
+            hip.instnorm_act_fwd(y_raw, stats, self.gamma, self.beta, a, self.slope, self.eps, residual)
+            hip.maxpool2_fwd(a, pooled)
+            return a, stats
         hip.instnorm_act_fwd(y_raw, stats, self.gamma, self.beta, a, self.slope, self.eps, residual)
         return a, stats
 
@@ -425,9 +433,9 @@ class ConvNormAct:
     def __init__(self, conv: Conv3, norm: InstNormAct):
         self.conv, self.norm = conv, norm
 
-    def fwd(self, x, out=None):
+    def fwd(self, x, out=None, pooled=None):
         y, stats = self.conv.fwd(x, want_stats=True)
-        a, stats = self.norm.fwd(y, out, stats=stats)
+        a, stats = self.norm.fwd(y, out, stats=stats, pooled=pooled)
         return a, (x, y, stats, a)
 
     def bwd(self, saved, da, need_dx=True, red=None, next_saved=None, next_cna=None):

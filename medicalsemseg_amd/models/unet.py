@@ -165,15 +165,14 @@ class _UNetFn(torch.autograd.Function):
         cur = x
         skips = []
         for lvl, (c0, c1) in enumerate(net._enc):
-            if lvl > 0:
-                pooled_src = cur
-                cur = maxpool_fwd(cur)
             a0, s0 = c0.fwd(cur)
             out = cat[lvl][..., :f[lvl]] if lvl < 4 else None
-            a1, s1 = c1.fwd(a0, out)
+            # the level's output goes into the decoder's concat buffer and, max-pooled by the same kernel, to the next level
+            pooled = torch.empty(N, D >> (lvl + 1), H >> (lvl + 1), W >> (lvl + 1), f[lvl], dtype=T, device=dev) if lvl < 4 else None
+            a1, s1 = c1.fwd(a0, out, pooled=pooled)
             saved["enc"].append((s0, s1))
             skips.append(a1)
-            cur = a1
+            cur = pooled if lvl < 4 else a1
         # decoder: levels 3..0
         for j, (up, c0, c1) in enumerate(net._dec):
             lvl = 3 - j

@@ -506,3 +506,29 @@ def test_conv_dgrad_fused_instnorm_backward_reductions(dtype, cin, cout, sp, N):
     assert float((dyraw.float() - dyraw_ref.float()).abs().max()) / sc < tol
     for a, b, nm in ((ga.grad, g_ref, "dgamma"), (be.grad, b_ref, "dbeta")):
         assert float((a - b).abs().max()) / (float(b.abs().max()) + 1e-6) < 5e-4, nm
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,C", [((2, 8, 12, 16), 32), ((1, 6, 4, 10), 64), ((1, 2, 2, 2), 8)])
+def test_instnorm_act_pool_fwd_equals_two_kernels(dtype, shape, C):
+    """InstanceNorm + LeakyReLU + MaxPool3d(2) in one pass == instnorm_act_fwd followed by maxpool2_fwd, bit for bit
+    (activation written into the first half of a [skip | up] concat buffer, as the UNet encoder does)"""
+    from medicalsemseg_amd import hip
+    DEV = _dev()
+    N, D, H, W = shape
+    torch.manual_seed(11)
+    y = torch.randn(N, D, H, W, C, device=DEV).to(dtype)
+    gamma = torch.randn(C, device=DEV)
+    beta = torch.randn(C, device=DEV)
+    stats = hip.channel_stats(y)
+    cat_a = torch.zeros(N, D, H, W, 2 * C, device=DEV, dtype=dtype)
+    cat_b = torch.zeros_like(cat_a)
+    pool_a = torch.empty(N, D // 2, H // 2, W // 2, C, device=DEV, dtype=dtype)
+    pool_b = torch.empty_like(pool_a)
+    assert hip.instnorm_pool_ok(y, cat_a[..., :C], pool_a)
+    hip.instnorm_act_pool_fwd(y, stats, gamma, beta, cat_a[..., :C], pool_a, 0.1)
+    hip.instnorm_act_fwd(y, stats, gamma, beta, cat_b[..., :C], 0.1)
+    hip.maxpool2_fwd(cat_b[..., :C], pool_b)
+    assert torch.equal(cat_a, cat_b) and torch.equal(pool_a, pool_b)
+    ref = torch.nn.functional.max_pool3d(cat_b[..., :C].float().permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1)
+    assert torch.equal(pool_a.float(), ref)
