@@ -178,6 +178,15 @@ int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, con
 int msseg_instnorm_act_pool_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
                                 void* y, long long ldy, void* pooled, long long ldp, int N, int D, int H, int W, int C,
                                 float eps, float slope, int dtype, msseg_stream_t stream);
+/* Backward of that pair for an encoder level, first pass: da = skip + maxpool2_bwd(y, g) written densely (skip: the
+ * decoder's gradient of the level's output, g: gradient of the pooled tensor; y is recomputed from x, arg-max rule as
+ * msseg_maxpool2_bwd) and red[n][c] = (sum dz, sum dz*xhat) of da as msseg_instnorm_act_bwd_reduce(y == NULL) gives it,
+ * dgamma/dbeta likewise.  Follow with msseg_instnorm_act_bwd_apply(dy = da, red). */
+int msseg_instnorm_act_poolbwd_reduce(const void* x, long long ldx, const float* stats, const float* gamma,
+                                      const float* beta, const void* skip, long long lds, const void* g, long long ldg,
+                                      void* da, long long ldda, float* red, float* dgamma, float* dbeta, int accumulate,
+                                      int N, int D, int H, int W, int C, float eps, float slope, void* scratch,
+                                      size_t scratch_bytes, int dtype, msseg_stream_t stream);
 /* backward, pass 1: red[n][c] = (sum dz, sum dz*xhat), dz = dy * lrelu'(z): the sign of the pre-activation z is taken
  * from the forward output y, or -- y == NULL, layers without residual -- recomputed as x*rstd*gamma + beta - mean*...,
  * which saves one tensor read (gamma/beta = the forward's affine parameters, nullable);

@@ -591,6 +591,118 @@ __global__ __launch_bounds__(256) void instnorm_pool_fwd_kernel(const NormPoolPa
     }
 }
 
+// Backward counterpart for an encoder level: the gradient that reaches the level's activation a = lrelu(IN(x)) is
+// skip + maxpool_bwd(a, g) (the decoder's skip gradient plus the pooled path from the level below).  One thread owns a
+// 2x2x2 cell x one channel chunk: it recomputes the eight activations from x exactly as the forward stored them (the
+// arg-max of the cell, first maximum wins, NaN propagates: maxpool2_kernel's rule), writes
+// da = T(skip + [voxel is the arg-max] * g) to a dense tensor and accumulates the InstanceNorm-backward sums
+// (sum dz, sum dz * xhat), dz = da * lrelu'(pre-activation) -- what maxpool2_bwd followed by instnorm_kernel<MODE 1> do.
+struct NormPoolBwdParams {
+    const void* x; long long ldx;
+    const float* stats; const float* gamma; const float* beta;
+    const void* skip; long long lds;
+    const void* g; long long ldg;
+    void* da; long long ldda;
+    int N, D, H, W, C; float eps, slope;
+    int groups, rows_par; long long cells_per_block;
+    float* ws;
+};
+
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void instnorm_poolbwd_reduce_kernel(const NormPoolBwdParams p) {
+    constexpr int WD = DT<T>::EPC;
+    __shared__ float red[RED_THREADS * 2 * WD];
+    const int n = blockIdx.y;
+    const int g = threadIdx.x % p.groups, rl = threadIdx.x / p.groups;
+    const int OD = p.D / 2, OH = p.H / 2, OW = p.W / 2;
+    const long long cells = (long long)OD * OH * OW, S = (long long)p.D * p.H * p.W;
+    const long long c0 = (long long)blockIdx.x * p.cells_per_block;
+    long long c1 = c0 + p.cells_per_block;
+    if (c1 > cells) c1 = cells;
+    const T* xn = (const T*)p.x + (long long)n * S * p.ldx;
+    const T* sn = (const T*)p.skip + (long long)n * S * p.lds;
+    const T* gn = (const T*)p.g + (long long)n * cells * p.ldg;
+    T* dn = (T*)p.da + (long long)n * S * p.ldda;
+    for (int gbase = 0; gbase * WD < p.C; gbase += p.groups) {   // uniform trip count: barriers inside
+        const int gg = gbase + g;
+        const bool act = gg * WD < p.C;
+        float mean[WD], rstd[WD], sc[WD], sh[WD], a0[WD], a1[WD];
+#pragma unroll
+        for (int e = 0; e < WD; ++e) {
+            const int c = act ? gg * WD + e : 0;
+            mean_rstd(p.stats, n, p.C, c, S, p.eps, mean[e], rstd[e]);
+            sc[e] = rstd[e] * (p.gamma ? p.gamma[c] : 1.f);
+            sh[e] = (p.beta ? p.beta[c] : 0.f) - mean[e] * sc[e];
+            a0[e] = a1[e] = 0.f;
+        }
+        if (act && rl < p.rows_par) {
+            for (long long cell = c0 + rl; cell < c1; cell += p.rows_par) {
+                const int ow = (int)(cell % OW), oh = (int)((cell / OW) % OH), od = (int)(cell / ((long long)OW * OH));
+                Chunk<T> xin[8], gv;
+                Chunk<T> skin[8];
+                long long vox[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    vox[k] = ((long long)(2 * od + (k >> 2)) * p.H + 2 * oh + ((k >> 1) & 1)) * p.W + 2 * ow + (k & 1);
+                    xin[k].load(xn + vox[k] * p.ldx + gg * WD);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) skin[k].load(sn + vox[k] * p.lds + gg * WD);   // all 17 loads in flight together
+                gv.load(gn + cell * p.ldg + gg * WD);
+                float best[WD];
+                int arg[WD];
+#pragma unroll
+                for (int e = 0; e < WD; ++e) { best[e] = -INFINITY; arg[e] = 0; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                    for (int e = 0; e < WD; ++e) {
+                        const float z = xin[k].v[e] * sc[e] + sh[e];
+                        const float a = (float)(T)(z > 0.f ? z : z * p.slope);
+                        if (a > best[e] || a != a) { best[e] = a; arg[e] = k; }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    Chunk<T> o;
+#pragma unroll
+                    for (int e = 0; e < WD; ++e) {
+                        const float dv = (float)(T)(skin[k].v[e] + (arg[e] == k ? gv.v[e] : 0.f));
+                        o.v[e] = dv;
+                        const float z = xin[k].v[e] * sc[e] + sh[e];
+                        const float dz = z > 0.f ? dv : dv * p.slope;
+                        a0[e] += dz;
+                        a1[e] += dz * ((xin[k].v[e] - mean[e]) * rstd[e]);
+                    }
+                    o.store(dn + vox[k] * p.ldda + gg * WD);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < WD; ++e) {
+            red[(threadIdx.x * WD + e) * 2 + 0] = a0[e];
+            red[(threadIdx.x * WD + e) * 2 + 1] = a1[e];
+        }
+        __syncthreads();
+        block_rows_reduce<WD>(red, p.groups, p.rows_par, g, rl, act);
+        if (act && rl == 0) {
+            const int kmax = p.rows_par < RED_STAGE2 ? p.rows_par : RED_STAGE2;
+#pragma unroll
+            for (int e = 0; e < WD; ++e) {
+                float a = 0.f, b = 0.f;
+                for (int k = 0; k < kmax; ++k) {
+                    a += red[((k * p.groups + g) * WD + e) * 2 + 0];
+                    b += red[((k * p.groups + g) * WD + e) * 2 + 1];
+                }
+                float* wsb = p.ws + ((long long)n * gridDim.x + blockIdx.x) * p.C * 2;
+                wsb[(gg * WD + e) * 2 + 0] = a;
+                wsb[(gg * WD + e) * 2 + 1] = b;
+            }
+        }
+    }
+}
+
 template <typename T, int MODE> int launch_norm(NormParams& p, int N, bool vec, hipStream_t st) {
     constexpr int NTHR = MODE == 1 ? RED_THREADS : 256;
     const RowMap m = row_map(p.C, vec ? DT<T>::EPC : 1, NTHR);
@@ -998,6 +1110,40 @@ int msseg_instnorm_act_pool_fwd(const void* x, long long ldx, const float* stats
     DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_pool_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, p),
                hipLaunchKernelGGL(instnorm_pool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, p));
     MSSEG_CHECK_LAUNCH("instnorm_act_pool_fwd");
+    return MSSEG_OK;
+}
+
+int msseg_instnorm_act_poolbwd_reduce(const void* x, long long ldx, const float* stats, const float* gamma,
+                                      const float* beta, const void* skip, long long lds, const void* g, long long ldg,
+                                      void* da, long long ldda, float* red, float* dgamma, float* dbeta, int accumulate,
+                                      int N, int D, int H, int W, int C, float eps, float slope, void* scratch,
+                                      size_t scratch_bytes, int dtype, msseg_stream_t stream) {
+    if (!x || !stats || !skip || !g || !da || !red || N < 1 || D < 2 || H < 2 || W < 2 || C < 1)
+        MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_poolbwd_reduce: bad args");
+    if ((D | H | W) & 1) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_poolbwd_reduce: odd spatial size %dx%dx%d", D, H, W);
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_poolbwd_reduce: bad dtype");
+    if (int rc = scratch_ok(scratch, scratch_bytes, "instnorm_act_poolbwd_reduce")) return rc;
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    if (!(vec_ok(x, ldx, C, esz) && vec_ok(skip, lds, C, esz) && vec_ok(g, ldg, C, esz) && vec_ok(da, ldda, C, esz)))
+        MSSEG_FAIL(MSSEG_EINVAL, "instnorm_act_poolbwd_reduce: needs 16-byte aligned rows and a channel count multiple of %d",
+                   16 / esz);
+    NormPoolBwdParams p{x, ldx, stats, gamma, beta, skip, lds, g, ldg, da, ldda, N, D, H, W, C, eps, slope, 0, 0, 0, nullptr};
+    p.ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+    const RowMap m = row_map(C, 16 / esz, RED_THREADS);
+    p.groups = m.groups; p.rows_par = m.rows_par;
+    const long long cells = (long long)(D / 2) * (H / 2) * (W / 2);
+    // a cell is eight voxel rows of work: one cell per thread while the grid stays within one block per CU
+    long long blocks = reduce_blocks(cells * 8, m.rows_par, N, C, 2);
+    p.cells_per_block = ceil_div_ll(cells, blocks);
+    blocks = ceil_div_ll(cells, p.cells_per_block);
+    dim3 grid((unsigned)blocks, N);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(instnorm_poolbwd_reduce_kernel<float>, grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p),
+               hipLaunchKernelGGL(instnorm_poolbwd_reduce_kernel<bf16_t>, grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p));
+    MSSEG_CHECK_LAUNCH("instnorm_act_poolbwd_reduce");
+    FinalizeArgs a{p.ws, N, (int)blocks, C, 2, 2, red, dbeta, dgamma, accumulate};
+    hipLaunchKernelGGL(channels_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    MSSEG_CHECK_LAUNCH("channels_finalize");
     return MSSEG_OK;
 }
 

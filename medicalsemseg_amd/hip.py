@@ -66,6 +66,8 @@ SIGNATURES = {
     "msseg_deconv_k2s2_wgrad": ([_vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_channel_stats": ([_vp, _ll, _vp, _i, _ll, _i, _vp, _sz, _i, _vp], _i),
     "msseg_instnorm_act_fwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
+    "msseg_instnorm_act_poolbwd_reduce": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i,
+                                           _i, _i, _i, _i, _i, _f, _f, _vp, _sz, _i, _vp], _i),
     "msseg_instnorm_act_pool_fwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _f, _f, _i, _vp], _i),
     "msseg_instnorm_act_bwd_reduce": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _ll, _i, _f, _f, _vp, _sz, _i, _vp], _i),
     "msseg_instnorm_act_bwd_apply": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _ll, _vp, _ll, _i, _ll, _i, _f, _f, _i, _vp], _i),
@@ -509,6 +511,21 @@ def instnorm_act_pool_fwd(x, stats, gamma, beta, y, pooled, slope, eps=1e-5):
     _ck(lib().msseg_instnorm_act_pool_fwd(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(y), ld(y), _p(pooled), ld(pooled),
                                           N, D, H, W, Cc, eps, slope, dt(x), _stream()), "instnorm_act_pool_fwd")
     return y, pooled
+
+
+def instnorm_act_poolbwd_reduce(x, stats, gamma, beta, skip, g, da, slope, eps=1e-5, dgamma=None, dbeta=None,
+                                accumulate=False):
+    """da = skip + max_pool3d-backward(lrelu(instance_norm(x)), g) (dense) and the InstanceNorm-backward sums of da;
+    returns red[N][C][2].  Follow with instnorm_act_bwd_apply(x, ..., dy=da, red)."""
+    _need_gpu(x, stats, skip, g, da)
+    N, D, H, W, Cc = x.shape
+    red = torch.empty(N, Cc, 2, dtype=torch.float32, device=x.device)
+    sc = scratch(x.device)
+    _ck(lib().msseg_instnorm_act_poolbwd_reduce(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(skip), ld(skip), _p(g),
+                                                ld(g), _p(da), ld(da), _p(red), _p(dgamma), _p(dbeta), int(accumulate),
+                                                N, D, H, W, Cc, eps, slope, _p(sc), sc.numel(), dt(x), _stream()),
+        "instnorm_act_poolbwd_reduce")
+    return red
 
 
 def instnorm_act_bwd(x, stats, gamma, y, dy, dx, slope, eps=1e-5, dres=None, dgamma=None, dbeta=None,

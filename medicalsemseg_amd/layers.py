@@ -408,6 +408,19 @@ class InstNormAct:
         hip.instnorm_act_fwd(y_raw, stats, self.gamma, self.beta, a, self.slope, self.eps, residual)
         return a, stats
 
+    def pool_bwd_reduce(self, y_raw, stats, skip_grad, pooled_grad):
+        """Encoder level: the gradient of this layer's output is skip_grad + maxpool-backward(pooled_grad).  One kernel
+        forms it (dense) together with this layer's backward sums; returns (da, red) for `bwd(..., red=red)`, or None when
+        the shape is not eligible (the caller then runs maxpool2_bwd and the plain backward)."""
+        if (os.environ.get("MSSEG_NO_NORM_POOL") or os.environ.get("MSSEG_NO_POOL_BWD_FUSE")
+                or not hip.instnorm_pool_ok(y_raw, skip_grad, pooled_grad)):
+            return None
+        da = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device)
+        dg, db, acc = _norm_grad_bufs(self)
+        red = hip.instnorm_act_poolbwd_reduce(y_raw, stats, self.gamma, self.beta, skip_grad, pooled_grad, da, self.slope,
+                                              self.eps, dg, db, acc)
+        return da, red
+
     def bwd(self, y_raw, stats, a, da, want_dres=False, red=None):
         """red: reductions already produced by the kernel that made `da` (fused path) -> only the apply pass runs"""
         dy = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device)

@@ -266,11 +266,16 @@ class _UNetFn(torch.autograd.Function):
             s0, s1 = saved["enc"][lvl]
             if lvl == 1:
                 side.set_mode(side.INLINE)
+            red_in = red_c1 if lvl == 4 else None
             if lvl < 4:
-                # gradient of the skip (written by the decoder) + max-pool path from the level below
-                x_l = s1[3]
-                hip.maxpool2_bwd(x_l, g, skip_grads[lvl], accumulate=True)
-                g = skip_grads[lvl]
-            g, red = c1.bwd(s1, g, True, red=(red_c1 if lvl == 4 else None), next_saved=s0, next_cna=c0)
+                # gradient of the skip (written by the decoder) + max-pool path from the level below: formed by the kernel
+                # that also computes the second unit's InstanceNorm-backward sums
+                fused = c1.norm.pool_bwd_reduce(s1[1], s1[2], skip_grads[lvl], g)
+                if fused is not None:
+                    g, red_in = fused
+                else:
+                    hip.maxpool2_bwd(s1[3], g, skip_grads[lvl], accumulate=True)
+                    g = skip_grads[lvl]
+            g, red = c1.bwd(s1, g, True, red=red_in, next_saved=s0, next_cna=c0)
             g = c0.bwd(s0, g, need_dx=(lvl > 0), red=red)
         return g

@@ -532,3 +532,39 @@ def test_instnorm_act_pool_fwd_equals_two_kernels(dtype, shape, C):
     assert torch.equal(cat_a, cat_b) and torch.equal(pool_a, pool_b)
     ref = torch.nn.functional.max_pool3d(cat_b[..., :C].float().permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1)
     assert torch.equal(pool_a.float(), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,C", [((2, 8, 12, 16), 32), ((1, 6, 4, 10), 64), ((1, 2, 2, 2), 8), ((1, 16, 16, 16), 256)])
+def test_instnorm_act_poolbwd_reduce_equals_two_kernels(dtype, shape, C):
+    """skip + maxpool-backward and the InstanceNorm-backward sums in one pass == maxpool2_bwd(accumulate) followed by
+    instnorm_act_bwd_reduce: the gradient tensor bit for bit (skip gradient read from the first half of a concat-shaped
+    buffer, as in the UNet), the sums to fp32 summation-order rounding"""
+    from medicalsemseg_amd import hip
+    DEV = _dev()
+    N, D, H, W = shape
+    torch.manual_seed(12)
+    y = torch.randn(N, D, H, W, C, device=DEV).to(dtype)
+    gamma = torch.randn(C, device=DEV)
+    beta = torch.randn(C, device=DEV) * 0.3
+    stats = hip.channel_stats(y)
+    a = torch.empty_like(y)
+    pooled = torch.empty(N, D // 2, H // 2, W // 2, C, device=DEV, dtype=dtype)
+    hip.instnorm_act_pool_fwd(y, stats, gamma, beta, a, pooled, 0.1)
+    dcat = torch.randn(N, D, H, W, 2 * C, device=DEV).to(dtype)
+    g = torch.randn_like(pooled)
+    # reference: two kernels, in place in the concat-shaped gradient
+    ref_cat = dcat.clone()
+    hip.maxpool2_bwd(a, g, ref_cat[..., :C], accumulate=True)
+    dg_ref, db_ref = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx_ref = torch.empty_like(y)
+    red_ref = hip.instnorm_act_bwd(y, stats, gamma, None, ref_cat[..., :C], dx_ref, 0.1, 1e-5, None, dg_ref, db_ref, False, beta)
+    # fused
+    da = torch.empty_like(y)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    red = hip.instnorm_act_poolbwd_reduce(y, stats, gamma, beta, dcat[..., :C], g, da, 0.1, 1e-5, dg, db, False)
+    assert torch.equal(da, ref_cat[..., :C].contiguous())
+    scale = float(red_ref.abs().max())
+    assert float((red - red_ref).abs().max()) < 1e-5 * scale + 1e-6
+    assert float((dg - dg_ref).abs().max()) < 1e-5 * float(dg_ref.abs().max()) + 1e-6
+    assert float((db - db_ref).abs().max()) < 1e-5 * float(db_ref.abs().max()) + 1e-6
