@@ -170,6 +170,32 @@ def gen_lr_and_misc():
     _save("resample.npz", vol=vol, out=misc.resample_3d(vol, (9, 6, 11)))
 
 
+def gen_unetr_conv_blocks():
+    """conv / transposed-conv blocks of the reference's own UNETR decoder (models/segmentors/unetr.py:9-52, pure torch):
+    SingleConv3DBlock (Conv3d k3 p1 + bias), SingleDeconv3DBlock (ConvTranspose3d k2 s2 + bias) and Deconv3DBlock in eval
+    mode (deconv -> conv -> BatchNorm3d with its initial running statistics -> ReLU), forward and gradients."""
+    import models.segmentors.unetr as U
+    x = det_tensor("unetr_x", (2, 16, 12, 12, 12)).requires_grad_(True)
+    conv = U.SingleConv3DBlock(16, 32, 3)
+    det_fill_(conv, "unetr_conv.")
+    y = conv(x)
+    r = det_tensor("unetr_r", tuple(y.shape))
+    (y * r).sum().backward()
+    out = dict(conv_y=y, conv_dx=x.grad.clone(), conv_dw=conv.block.weight.grad, conv_db=conv.block.bias.grad)
+    x2 = det_tensor("unetr_x2", (2, 32, 6, 6, 6)).requires_grad_(True)
+    dec = U.SingleDeconv3DBlock(32, 16)
+    det_fill_(dec, "unetr_deconv.")
+    y2 = dec(x2)
+    r2 = det_tensor("unetr_r2", tuple(y2.shape))
+    (y2 * r2).sum().backward()
+    out.update(deconv_y=y2, deconv_dx=x2.grad.clone(), deconv_dw=dec.block.weight.grad, deconv_db=dec.block.bias.grad)
+    blk = U.Deconv3DBlock(32, 16).eval()
+    det_fill_(blk, "unetr_block.")
+    with torch.no_grad():
+        out["block_y"] = blk(x2.detach())
+    _save("unetr_blocks.npz", **out)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("needs /root/reference (build container only)")
@@ -181,6 +207,7 @@ def main():
     gen_basic_layer_mask(ref)
     gen_encoder(ref)
     gen_lr_and_misc()
+    gen_unetr_conv_blocks()
 
 
 if __name__ == "__main__":

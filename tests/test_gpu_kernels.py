@@ -568,3 +568,41 @@ def test_instnorm_act_poolbwd_reduce_equals_two_kernels(dtype, shape, C):
     assert float((red - red_ref).abs().max()) < 1e-5 * scale + 1e-6
     assert float((dg - dg_ref).abs().max()) < 1e-5 * float(dg_ref.abs().max()) + 1e-6
     assert float((db - db_ref).abs().max()) < 1e-5 * float(db_ref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_and_deconv_vs_reference_unetr_blocks(dtype):
+    """HIP conv3d k3 / ConvTranspose3d k2 s2 (forward, input, weight and bias gradients) against outputs of the REFERENCE's
+    own UNETR decoder blocks (tests/golden/unetr_blocks.npz, made by oracle/gen_golden.py from
+    /root/reference/models/segmentors/unetr.py:9-52); fp32 gate 1e-4 of the output scale, bf16 reported to 2e-2."""
+    import os
+    from medicalsemseg_amd import layers
+    from tests.test_oracle_golden import _unetr_params
+    from tests.golden_util import det_tensor
+    DEV = _dev()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "unetr_blocks.npz"))
+    P = {k: torch.nn.Parameter(v.to(DEV)) for k, v in _unetr_params().items()}
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+
+    def rel(got, key):
+        ref = torch.from_numpy(g[key])
+        return float((got.detach().float().cpu() - ref).abs().max()) / float(ref.abs().max())
+
+    x = cl(det_tensor("unetr_x", (2, 16, 12, 12, 12)), dtype, DEV)
+    r = cl(det_tensor("unetr_r", (2, 32, 12, 12, 12)), dtype, DEV)
+    conv = layers.Conv3(P["conv_w"], P["conv_b"])
+    y = conv.fwd(x)
+    dx = conv.bwd(x, r, need_dx=True)
+    assert rel(ncdhw(y), "conv_y") < tol and rel(ncdhw(dx), "conv_dx") < tol
+    assert rel(P["conv_w"].grad, "conv_dw") < tol and rel(P["conv_b"].grad, "conv_db") < tol
+    x2 = cl(det_tensor("unetr_x2", (2, 32, 6, 6, 6)), dtype, DEV)
+    r2 = cl(det_tensor("unetr_r2", (2, 16, 12, 12, 12)), dtype, DEV)
+    dec = layers.Deconv2(P["deconv_w"], P["deconv_b"])
+    y2 = dec.fwd(x2)
+    dx2 = dec.bwd(x2, r2, need_dx=True)
+    assert rel(ncdhw(y2), "deconv_y") < tol and rel(ncdhw(dx2), "deconv_dx") < tol
+    assert rel(P["deconv_w"].grad, "deconv_dw") < tol and rel(P["deconv_b"].grad, "deconv_db") < tol
+    # Deconv3DBlock in eval mode: deconv -> conv on the HIP kernels, BatchNorm (initial running statistics) + ReLU as torch ops
+    t = layers.Conv3(P["blk_cw"], P["blk_cb"]).fwd(layers.Deconv2(P["blk_dw"], P["blk_db"]).fwd(x2)).float()
+    t = torch.relu(t / np.sqrt(1.0 + 1e-5) * P["blk_bn_w"] + P["blk_bn_b"])
+    assert rel(ncdhw(t), "block_y") < tol

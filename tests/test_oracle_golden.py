@@ -78,3 +78,39 @@ def test_encoder(golden_dir, tag, vol):
     _close(m.layers[0].blocks[1].attn.qkv.weight.grad, g["d_qkv_w"], rtol=1e-3, atol=2e-2)
     _close(m.layers[0].blocks[1].attn.relative_position_bias_table.grad, g["d_table"], rtol=1e-3, atol=1e-2)
     _close(m.layers[1].downsample.reduction.weight.grad[:8], g["d_merge_w"], rtol=1e-3, atol=1e-2)
+
+
+def _unetr_params():
+    """the deterministic fills oracle/gen_golden.py applied to the reference's blocks (golden_util.det_fill_ rules)"""
+    def mat(tag, shape):
+        return det_tensor(tag, shape, 1.0 / np.sqrt(int(np.prod(shape[1:])))).float()   # det_fill_ copies into fp32 parameters
+    return {
+        "conv_w": mat("unetr_conv.block.weight", (32, 16, 3, 3, 3)), "conv_b": det_tensor("unetr_conv.block.bias", (32,), 0.1),
+        "deconv_w": mat("unetr_deconv.block.weight", (32, 16, 2, 2, 2)), "deconv_b": det_tensor("unetr_deconv.block.bias", (16,), 0.1),
+        "blk_dw": mat("unetr_block.block.0.block.weight", (32, 16, 2, 2, 2)), "blk_db": det_tensor("unetr_block.block.0.block.bias", (16,), 0.1),
+        "blk_cw": mat("unetr_block.block.1.block.weight", (16, 16, 3, 3, 3)), "blk_cb": det_tensor("unetr_block.block.1.block.bias", (16,), 0.1),
+        "blk_bn_w": det_tensor("unetr_block.block.2.weight", (16,), 0.1, 1.0), "blk_bn_b": det_tensor("unetr_block.block.2.bias", (16,), 0.1),
+    }
+
+
+def test_unetr_conv_blocks(golden_dir):
+    """The stock torch ops the oracle is built from (conv3d k3 p1, conv_transpose3d k2 s2, eval BatchNorm + ReLU)
+    reproduce the reference's own UNETR decoder blocks (/root/reference/models/segmentors/unetr.py:9-52)."""
+    import torch.nn.functional as F
+    g = _load(golden_dir, "unetr_blocks.npz")
+    P = _unetr_params()
+    x = det_tensor("unetr_x", (2, 16, 12, 12, 12)).requires_grad_(True)
+    w, b = P["conv_w"].clone().requires_grad_(True), P["conv_b"].clone().requires_grad_(True)
+    y = F.conv3d(x, w, b, padding=1)
+    (y * det_tensor("unetr_r", tuple(y.shape))).sum().backward()
+    _close(y, g["conv_y"]); _close(x.grad, g["conv_dx"]); _close(w.grad, g["conv_dw"], 1e-4, 1e-4); _close(b.grad, g["conv_db"], 1e-4, 1e-4)
+    x2 = det_tensor("unetr_x2", (2, 32, 6, 6, 6)).requires_grad_(True)
+    w2, b2 = P["deconv_w"].clone().requires_grad_(True), P["deconv_b"].clone().requires_grad_(True)
+    y2 = F.conv_transpose3d(x2, w2, b2, stride=2)
+    (y2 * det_tensor("unetr_r2", tuple(y2.shape))).sum().backward()
+    _close(y2, g["deconv_y"]); _close(x2.grad, g["deconv_dx"]); _close(w2.grad, g["deconv_dw"], 1e-4, 1e-4)
+    _close(b2.grad, g["deconv_db"], 1e-4, 1e-4)
+    with torch.no_grad():
+        t = F.conv3d(F.conv_transpose3d(x2, P["blk_dw"], P["blk_db"], stride=2), P["blk_cw"], P["blk_cb"], padding=1)
+        t = torch.relu(t / np.sqrt(1.0 + 1e-5) * P["blk_bn_w"].view(1, -1, 1, 1, 1) + P["blk_bn_b"].view(1, -1, 1, 1, 1))
+    _close(t, g["block_y"])
