@@ -111,6 +111,11 @@ int msseg_conv3d_stem_fwd(const void* x, long long ldx, const void* wp, const fl
 /* Conv3d k=1 (UnetResBlock.conv3, UnetOutBlock models/segmentors/swin_unetr.py:130, BasicUNet final_conv). */
 int msseg_conv3d_k1_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                         long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
+/* The same for a segmentation head with 1..4 output channels (UnetOutBlock / final_conv with 2-4 classes): a streaming
+ * kernel, w = the layer's fp32 weight [Cout][Cin] as it is (no packed image), Cin <= 64 in 16-byte chunks.
+ * MSSEG_EINVAL for other shapes (use msseg_conv3d_k1_fwd). */
+int msseg_conv3d_k1_head_fwd(const void* x, long long ldx, const float* w, const float* bias, void* y, long long ldy,
+                             long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
 /* Conv3d with few input channels (Cin*k^3 <= 128), kernel k, stride s, pad p, gathered im2col-style:
  * the 1->C stem convs and PatchEmbed3D.proj (models/blocks/patch_embeddings.py:109). */
 int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,

@@ -932,6 +932,39 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const msseg_pac
     }
 }
 
+// 1x1x1 convolution with a handful of output channels (the segmentation head: 32 -> 2..8 classes).  The implicit-GEMM
+// kernels spend a 16-wide MFMA column block on three real outputs; this is a streaming pass instead: one thread per
+// voxel reads its Cin channels (16-byte chunks), the weights sit in LDS (same address for every lane: broadcast reads),
+// fp32 accumulation, weights rounded to T first so the arithmetic equals the MFMA path's up to summation order.
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void conv1x1_head_kernel(const T* __restrict__ x, long long ldx, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, T* __restrict__ y, long long ldy,
+                                                           long long NV, int Cin) {
+    constexpr int WD = DT<T>::EPC;
+    __shared__ float wS[COUT * 64];
+    for (int i = threadIdx.x; i < COUT * Cin; i += 256) wS[i] = (float)(T)w[i];
+    __syncthreads();
+    float b[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) b[c] = bias ? bias[c] : 0.f;
+    for (long long v = blockIdx.x * 256LL + threadIdx.x; v < NV; v += (long long)gridDim.x * 256) {
+        float acc[COUT];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = b[c];
+        const T* xr = x + v * ldx;
+        for (int k0 = 0; k0 < Cin; k0 += WD) {
+            Chunk<T> xc; xc.load(xr + k0);
+#pragma unroll
+            for (int c = 0; c < COUT; ++c)
+#pragma unroll
+                for (int e = 0; e < WD; ++e) acc[c] += xc.v[e] * wS[c * Cin + k0 + e];
+        }
+        T* yr = y + v * ldy;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) DT<T>::st(yr + c, acc[c]);
+    }
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, const uint8_t* __restrict__ decay, long long n, float lr, float b1,
                              float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* gscale,
@@ -1091,6 +1124,24 @@ int msseg_instnorm_act_fwd(const void* x, long long ldx, const float* stats, con
     const bool vec = vec_ok(x, ldx, C, esz) && vec_ok(y, ldy, C, esz) && (!residual || vec_ok(residual, ldr, C, esz));
     DISPATCH_T(dtype, return (launch_norm<float, 0>(p, N, vec, (hipStream_t)stream)),
                return (launch_norm<bf16_t, 0>(p, N, vec, (hipStream_t)stream)));
+}
+
+int msseg_conv3d_k1_head_fwd(const void* x, long long ldx, const float* w, const float* bias, void* y, long long ldy,
+                             long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+    if (!x || !w || !y || NV < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head: bad args");
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head: bad dtype");
+    if (Cout < 1 || Cout > 4 || Cin < 1 || Cin > 64 || !vec_ok(x, ldx, Cin, esz) || ldy < Cout)
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head: needs 1 <= Cout <= 4, Cin <= 64 in 16-byte chunks (got %d -> %d)", Cin, Cout);
+    const int g = grid_for(NV, 1);
+#define HEAD(T_, C_) hipLaunchKernelGGL((conv1x1_head_kernel<T_, C_>), dim3(g), dim3(256), 0, (hipStream_t)stream, \
+                                        (const T_*)x, ldx, w, bias, (T_*)y, ldy, NV, Cin)
+#define HEAD_C(T_) do { if (Cout == 1) HEAD(T_, 1); else if (Cout == 2) HEAD(T_, 2); else if (Cout == 3) HEAD(T_, 3); else HEAD(T_, 4); } while (0)
+    DISPATCH_T(dtype, HEAD_C(float), HEAD_C(bf16_t));
+#undef HEAD_C
+#undef HEAD
+    MSSEG_CHECK_LAUNCH("conv3d_k1_head");
+    return MSSEG_OK;
 }
 
 int msseg_instnorm_act_pool_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,

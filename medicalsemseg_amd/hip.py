@@ -55,6 +55,7 @@ SIGNATURES = {
     "msseg_gelu_fwd": ([_vp, _vp, _ll, _i, _vp], _i),
     "msseg_gelu_bwd": ([_vp, _vp, _vp, _ll, _i, _vp], _i),
     "msseg_conv3d_stem_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
+    "msseg_conv3d_k1_head_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_k1_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_gather_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_deconv_k2s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -340,6 +341,15 @@ def conv3d_k3_dgrad_inbwd(dy, wp, da, cin, cout, yraw, act, fwd_stats, slope, ep
         key += "/v%d" % lib().msseg_conv3d_k3_kernel(N, D, H, W, cin, cout, dt(dy))
     TIMER.launch(key, 2.0 * nv * 27 * cin * cout, nv * (cin + 3 * cout) * esz + 27 * cin * cout * esz, go)
     return red
+
+
+def conv3d_k1_head(x, w, bias, y, cin, cout):
+    """1x1x1 conv with 1..4 output channels straight from the fp32 weight [cout, cin] (streaming kernel)"""
+    _need_gpu(x, w, y)
+    nv = x.numel() // x.shape[-1]
+    _ck(lib().msseg_conv3d_k1_head_fwd(_p(x), ld(x), _p(w), _p(bias), _p(y), ld(y), nv, cin, cout, dt(x), _stream()),
+        "conv3d_k1_head_fwd")
+    return y
 
 
 def conv3d_k1(x, wp, bias, y, cin, cout):

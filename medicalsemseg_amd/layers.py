@@ -300,6 +300,10 @@ class Conv1:
         if self._gather(dtype):
             wp = self.cache.get(self.w, dtype, "g", lambda: hip.pack_conv_gather(self.w.detach(), dtype))
             hip.conv3d_gather(x, wp, self.b, y, self.cin, self.cout, 1, 1, 0)
+        elif (self.cout <= 4 and self.cin <= 64 and x.shape[-1] == self.cin and self.w.is_contiguous()
+              and not os.environ.get("MSSEG_NO_HEAD_KERNEL")):
+            # segmentation head (2-4 classes): streaming kernel on the fp32 weight as it is
+            hip.conv3d_k1_head(x, self.w.detach(), self.b, y, self.cin, self.cout)
         else:
             wp = self.cache.get(self.w, dtype, "f",
                                 lambda: hip.pack_conv_k1(self.w.detach().reshape(self.cout, self.cin), dtype))

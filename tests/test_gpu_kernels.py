@@ -606,3 +606,22 @@ def test_conv_and_deconv_vs_reference_unetr_blocks(dtype):
     t = layers.Conv3(P["blk_cw"], P["blk_cb"]).fwd(layers.Deconv2(P["blk_dw"], P["blk_db"]).fwd(x2)).float()
     t = torch.relu(t / np.sqrt(1.0 + 1e-5) * P["blk_bn_w"] + P["blk_bn_b"])
     assert rel(ncdhw(t), "block_y") < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout", [(32, 3), (48, 3), (8, 1), (64, 4), (32, 2)])
+def test_conv3d_k1_head(dtype, cin, cout):
+    """segmentation-head kernel (1x1x1 conv, <= 4 classes, fp32 weight as it is) vs F.conv3d on the rounded operands;
+    output written into the first channels of 8-channel rows, as the UNet does with its logits buffer"""
+    from medicalsemseg_amd import hip
+    DEV = _dev()
+    x = gen(2, cin, 6, 10, 12, seed=31)
+    w = gen(cout, cin, 1, 1, 1, seed=32, scale=0.2)
+    b = gen(cout, seed=33)
+    xr, wr = rnd(dtype, x, w)
+    ref = F.conv3d(xr, wr, b)
+    xc = cl(x, dtype, DEV)
+    buf = torch.full((2, 6, 10, 12, 8), 7.0, device=DEV, dtype=dtype)
+    hip.conv3d_k1_head(xc, w.to(DEV).reshape(cout, cin), b.to(DEV), buf[..., :cout], cin, cout)
+    check(ncdhw(buf[..., :cout]), ref, dtype, "conv3d_k1_head")
+    assert bool((buf[..., cout:] == 7.0).all())          # the padding channels are not touched
