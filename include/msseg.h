@@ -116,6 +116,15 @@ int msseg_conv3d_k1_fwd(const void* x, long long ldx, const void* wp, const floa
  * MSSEG_EINVAL for other shapes (use msseg_conv3d_k1_fwd). */
 int msseg_conv3d_k1_head_fwd(const void* x, long long ldx, const float* w, const float* bias, void* y, long long ldy,
                              long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
+/* Its input gradient fused with the InstanceNorm-backward sums of the layer that feeds the head (as
+ * msseg_conv3d_k1_dgrad_inbwd, same streaming form): da[v][c] = sum_k dy[v][k] * w[k][c] for the C channels of that
+ * layer, red[n][c] = (sum dz, sum dz*xhat) with the LeakyReLU sign recomputed from yraw (gamma, beta nullable),
+ * dgamma/dbeta written or accumulated.  dy rows 16-byte aligned with >= 4 readable channels (classes zero-padded). */
+int msseg_conv3d_k1_head_dgrad_inbwd(const void* dy, long long lddy, const float* w, void* da, long long ldda, int N,
+                                     long long S, int C, int Cout, const void* yraw, long long ldyraw,
+                                     const float* fwd_stats, const float* gamma, const float* beta, float slope, float eps,
+                                     float* red, float* dgamma, float* dbeta, int accumulate, void* scratch,
+                                     size_t scratch_bytes, int dtype, msseg_stream_t stream);
 /* Conv3d with few input channels (Cin*k^3 <= 128), kernel k, stride s, pad p, gathered im2col-style:
  * the 1->C stem convs and PatchEmbed3D.proj (models/blocks/patch_embeddings.py:109). */
 int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,

@@ -703,6 +703,94 @@ __global__ __launch_bounds__(RED_THREADS) void instnorm_poolbwd_reduce_kernel(co
     }
 }
 
+// Input gradient of the segmentation head (1x1x1 conv, <= 4 classes) fused with the InstanceNorm-backward sums of the
+// layer whose activation a = lrelu(IN(x)) feeds the head: da[v][c] = T(sum_k dy[v][k] * w[k][c]) and
+// (sum dz, sum dz * xhat), dz = da * lrelu'(pre-activation recomputed from x).  A streaming pass (thread = voxel x
+// 16-byte channel chunk) with the reduction scheme of instnorm_kernel<MODE 1>; replaces a 16-wide MFMA column block fed
+// with three real rows, and reads neither the packed weights nor the stored activation.
+struct HeadBwdParams {
+    const void* dy; long long lddy;
+    const float* w;                      // [Cout][C] fp32
+    const void* x; long long ldx;        // raw conv output of the receiving layer
+    const float* stats; const float* gamma; const float* beta;
+    void* da; long long ldda;
+    long long S; int C, Cout; float eps, slope;
+    int groups, rows_par; long long rows_per_block;
+    float* ws;
+};
+
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void head_dgrad_inbwd_kernel(const HeadBwdParams p) {
+    constexpr int WD = DT<T>::EPC;
+    __shared__ float red[RED_THREADS * 2 * WD];
+    const int n = blockIdx.y;
+    const int g = threadIdx.x % p.groups, rl = threadIdx.x / p.groups;
+    const long long r0 = (long long)blockIdx.x * p.rows_per_block;
+    long long r1 = r0 + p.rows_per_block;
+    if (r1 > p.S) r1 = p.S;
+    const T* xn = (const T*)p.x + (long long)n * p.S * p.ldx;
+    const T* dyn = (const T*)p.dy + (long long)n * p.S * p.lddy;
+    T* dan = (T*)p.da + (long long)n * p.S * p.ldda;
+    for (int gbase = 0; gbase * WD < p.C; gbase += p.groups) {   // uniform trip count: barriers inside
+        const int gg = gbase + g;
+        const bool act = gg * WD < p.C;
+        float mean[WD], rstd[WD], sc[WD], sh[WD], a0[WD], a1[WD], wv[4][WD];
+#pragma unroll
+        for (int e = 0; e < WD; ++e) {
+            const int c = act ? gg * WD + e : 0;
+            mean_rstd(p.stats, n, p.C, c, p.S, p.eps, mean[e], rstd[e]);
+            sc[e] = rstd[e] * (p.gamma ? p.gamma[c] : 1.f);
+            sh[e] = (p.beta ? p.beta[c] : 0.f) - mean[e] * sc[e];
+            a0[e] = a1[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wv[k][e] = k < p.Cout ? (float)(T)p.w[k * p.C + c] : 0.f;
+        }
+        if (act && rl < p.rows_par) {
+#pragma unroll 4
+            for (long long r = r0 + rl; r < r1; r += p.rows_par) {
+                Chunk<T> xc, dc, o;
+                xc.load(xn + r * p.ldx + gg * WD);
+                dc.load(dyn + r * p.lddy);            // the first EPC (>= 4) channels of the class gradient
+#pragma unroll
+                for (int e = 0; e < WD; ++e) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc += dc.v[k] * wv[k][e];
+                    const float da = (float)(T)acc;
+                    o.v[e] = da;
+                    const float z = xc.v[e] * sc[e] + sh[e];
+                    const float dz = z > 0.f ? da : da * p.slope;
+                    a0[e] += dz;
+                    a1[e] += dz * ((xc.v[e] - mean[e]) * rstd[e]);
+                }
+                o.store(dan + r * p.ldda + gg * WD);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < WD; ++e) {
+            red[(threadIdx.x * WD + e) * 2 + 0] = a0[e];
+            red[(threadIdx.x * WD + e) * 2 + 1] = a1[e];
+        }
+        __syncthreads();
+        block_rows_reduce<WD>(red, p.groups, p.rows_par, g, rl, act);
+        if (act && rl == 0) {
+            const int kmax = p.rows_par < RED_STAGE2 ? p.rows_par : RED_STAGE2;
+#pragma unroll
+            for (int e = 0; e < WD; ++e) {
+                float a = 0.f, b = 0.f;
+                for (int k = 0; k < kmax; ++k) {
+                    a += red[((k * p.groups + g) * WD + e) * 2 + 0];
+                    b += red[((k * p.groups + g) * WD + e) * 2 + 1];
+                }
+                float* wsb = p.ws + ((long long)n * gridDim.x + blockIdx.x) * p.C * 2;
+                wsb[(gg * WD + e) * 2 + 0] = a;
+                wsb[(gg * WD + e) * 2 + 1] = b;
+            }
+        }
+    }
+}
+
 template <typename T, int MODE> int launch_norm(NormParams& p, int N, bool vec, hipStream_t st) {
     constexpr int NTHR = MODE == 1 ? RED_THREADS : 256;
     const RowMap m = row_map(p.C, vec ? DT<T>::EPC : 1, NTHR);
@@ -1141,6 +1229,37 @@ int msseg_conv3d_k1_head_fwd(const void* x, long long ldx, const float* w, const
 #undef HEAD_C
 #undef HEAD
     MSSEG_CHECK_LAUNCH("conv3d_k1_head");
+    return MSSEG_OK;
+}
+
+int msseg_conv3d_k1_head_dgrad_inbwd(const void* dy, long long lddy, const float* w, void* da, long long ldda, int N,
+                                     long long S, int C, int Cout, const void* yraw, long long ldyraw,
+                                     const float* fwd_stats, const float* gamma, const float* beta, float slope, float eps,
+                                     float* red, float* dgamma, float* dbeta, int accumulate, void* scratch,
+                                     size_t scratch_bytes, int dtype, msseg_stream_t stream) {
+    if (!dy || !w || !da || !yraw || !fwd_stats || !red || N < 1 || S < 1)
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_dgrad_inbwd: bad args");
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_dgrad_inbwd: bad dtype");
+    if (int rc = scratch_ok(scratch, scratch_bytes, "conv3d_k1_head_dgrad_inbwd")) return rc;
+    const int esz = dtype == MSSEG_F32 ? 4 : 2, epc = 16 / esz;
+    if (Cout < 1 || Cout > 4 || C < 1 || !vec_ok(yraw, ldyraw, C, esz) || !vec_ok(da, ldda, C, esz) ||
+        (lddy % epc) || ((uintptr_t)dy & 15))
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_dgrad_inbwd: needs <= 4 classes in 16-byte aligned gradient rows and "
+                                 "16-byte channel chunks (C=%d, Cout=%d, lddy=%lld)", C, Cout, lddy);
+    HeadBwdParams p{dy, lddy, w, yraw, ldyraw, fwd_stats, gamma, beta, da, ldda, S, C, Cout, eps, slope, 0, 0, 0, nullptr};
+    p.ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+    const RowMap m = row_map(C, epc, RED_THREADS);
+    p.groups = m.groups; p.rows_par = m.rows_par;
+    long long blocks = reduce_blocks(S, m.rows_par, N, C, 2);
+    p.rows_per_block = ceil_div_ll(S, blocks);
+    blocks = ceil_div_ll(S, p.rows_per_block);
+    dim3 grid((unsigned)blocks, N);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_dgrad_inbwd_kernel<float>, grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p),
+               hipLaunchKernelGGL(head_dgrad_inbwd_kernel<bf16_t>, grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p));
+    MSSEG_CHECK_LAUNCH("conv3d_k1_head_dgrad_inbwd");
+    FinalizeArgs a{p.ws, N, (int)blocks, C, 2, 2, red, dbeta, dgamma, accumulate};
+    hipLaunchKernelGGL(channels_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    MSSEG_CHECK_LAUNCH("channels_finalize");
     return MSSEG_OK;
 }
 

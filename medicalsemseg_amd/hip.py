@@ -55,6 +55,8 @@ SIGNATURES = {
     "msseg_gelu_fwd": ([_vp, _vp, _ll, _i, _vp], _i),
     "msseg_gelu_bwd": ([_vp, _vp, _vp, _ll, _i, _vp], _i),
     "msseg_conv3d_stem_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
+    "msseg_conv3d_k1_head_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _ll, _i, _i, _vp, _ll, _vp, _vp, _vp, _f, _f, _vp, _vp,
+                                          _vp, _i, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_k1_head_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_k1_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_gather_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -350,6 +352,22 @@ def conv3d_k1_head(x, w, bias, y, cin, cout):
     _ck(lib().msseg_conv3d_k1_head_fwd(_p(x), ld(x), _p(w), _p(bias), _p(y), ld(y), nv, cin, cout, dt(x), _stream()),
         "conv3d_k1_head_fwd")
     return y
+
+
+def conv3d_k1_head_dgrad_inbwd(dy, w, da, cin, cout, yraw, fwd_stats, gamma, beta, slope, eps, dgamma=None, dbeta=None,
+                               accumulate=False):
+    """da = dy . w for a head with `cout` <= 4 classes (w fp32 [cout, cin]) and the InstanceNorm-backward sums of the layer
+    (yraw, fwd_stats, gamma, beta) that receives da.  Returns red[N][cin][2]."""
+    _need_gpu(dy, w, da, yraw, fwd_stats)
+    N = dy.shape[0]
+    S = dy.numel() // dy.shape[-1] // N
+    red = torch.empty(N, cin, 2, dtype=torch.float32, device=dy.device)
+    sc = scratch(dy.device)
+    _ck(lib().msseg_conv3d_k1_head_dgrad_inbwd(_p(dy), ld(dy), _p(w), _p(da), ld(da), N, S, cin, cout, _p(yraw), ld(yraw),
+                                               _p(fwd_stats), _p(gamma), _p(beta), slope, eps, _p(red), _p(dgamma),
+                                               _p(dbeta), int(accumulate), _p(sc), sc.numel(), dt(dy), _stream()),
+        "conv3d_k1_head_dgrad_inbwd")
+    return red
 
 
 def conv3d_k1(x, wp, bias, y, cin, cout):

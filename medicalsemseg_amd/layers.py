@@ -330,11 +330,20 @@ class Conv1:
             return None
         if self._gather(dtype):
             raise NotImplementedError("input gradient of a few-channel 1x1 conv is never needed on this path")
-        wp = self.cache.get(self.w, dtype, "d",
-                            lambda: hip.pack_conv_k1(self.w.detach().reshape(self.cout, self.cin), dtype, dgrad=True))
         dx = _empty_like_vol(dy, self.cin)
         kpad = dy_channels if dy_channels is not None else self.cout
         dyk = dy if dy_channels is None else dy[..., :kpad]
+        epc = 16 // dy.element_size()
+        if (next_norm is not None and self.cout <= 4 and kpad >= 4 and self.cin % epc == 0 and hip.ld(dyk) % epc == 0
+                and dyk.data_ptr() % 16 == 0 and self.w.is_contiguous() and not os.environ.get("MSSEG_NO_HEAD_KERNEL")):
+            # segmentation head: streaming kernel on the fp32 weight, with the receiving layer's backward sums
+            nrm, yraw, stats, act = next_norm
+            dg, db, acc = _norm_grad_bufs(nrm)
+            red = hip.conv3d_k1_head_dgrad_inbwd(dyk, self.w.detach(), dx, self.cin, self.cout, yraw, stats, nrm.gamma,
+                                                 nrm.beta, nrm.slope, nrm.eps, dg, db, acc)
+            return dx, red
+        wp = self.cache.get(self.w, dtype, "d",
+                            lambda: hip.pack_conv_k1(self.w.detach().reshape(self.cout, self.cin), dtype, dgrad=True))
         if next_norm is not None:
             nrm, yraw, stats, act = next_norm
             if dy.shape[0] <= 8 and self.cin % 4 == 0:

@@ -625,3 +625,42 @@ def test_conv3d_k1_head(dtype, cin, cout):
     hip.conv3d_k1_head(xc, w.to(DEV).reshape(cout, cin), b.to(DEV), buf[..., :cout], cin, cout)
     check(ncdhw(buf[..., :cout]), ref, dtype, "conv3d_k1_head")
     assert bool((buf[..., cout:] == 7.0).all())          # the padding channels are not touched
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout", [(32, 3), (48, 2), (64, 4)])
+def test_conv3d_k1_head_dgrad_inbwd(dtype, cin, cout):
+    """streaming head input-gradient + InstanceNorm-backward sums vs the torch fp32 formulas on the rounded operands"""
+    from medicalsemseg_amd import hip
+    DEV = _dev()
+    N, sp = 2, (6, 10, 12)
+    S = sp[0] * sp[1] * sp[2]
+    yraw = gen(N, cin, *sp, seed=41)
+    dl = gen(N, cout, *sp, seed=42)
+    w = gen(cout, cin, seed=43, scale=0.2)
+    gamma, beta = gen(cin, seed=44) * 0.3 + 1.0, gen(cin, seed=45) * 0.3
+    yr, dlr, wr = rnd(dtype, yraw, dl, w)
+    # reference (fp32, NCDHW): da = dl . w, rounded as stored; z from the stored raw output
+    da = torch.einsum("nkdhw,kc->ncdhw", dlr, wr)
+    da = rnd(dtype, da)
+    mean = yr.mean(dim=(2, 3, 4), keepdim=True)
+    var = (yr * yr).mean(dim=(2, 3, 4), keepdim=True) - mean * mean
+    rstd = torch.rsqrt(var.clamp_min(0) + 1e-5)
+    z = (yr - mean) * rstd * gamma.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1)
+    dz = torch.where(z > 0, da, da * 0.1)
+    red_ref = torch.stack([dz.sum(dim=(2, 3, 4)), (dz * (yr - mean) * rstd).sum(dim=(2, 3, 4))], dim=-1)
+    # HIP
+    yc = cl(yraw, dtype, DEV)
+    dlc = torch.zeros(N, *sp, 8, device=DEV, dtype=dtype)
+    dlc[..., :cout] = cl(dl, dtype, DEV)
+    stats = hip.channel_stats(yc)
+    dx = torch.empty_like(yc)
+    dg, db = torch.zeros(cin, device=DEV), torch.zeros(cin, device=DEV)
+    red = hip.conv3d_k1_head_dgrad_inbwd(dlc, w.to(DEV), dx, cin, cout, yc, stats, gamma.to(DEV), beta.to(DEV), 0.1, 1e-5,
+                                         dg, db, False)
+    check(ncdhw(dx), da, dtype, "head dgrad")
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    sc = float(red_ref.abs().max())
+    assert float((red.cpu() - red_ref).abs().max()) / sc < tol
+    assert float((db.cpu() - red_ref[..., 0].sum(0)).abs().max()) / sc < tol
+    assert float((dg.cpu() - red_ref[..., 1].sum(0)).abs().max()) / sc < tol
