@@ -1,13 +1,15 @@
 #!/usr/bin/env python
-"""Headline benchmark: 96^3 volumes/s of UNet (MONAI BasicUNet 1->3) forward + DiceCE + backward + AdamW,
-bf16, per-GPU batch 2 (BASELINE.json configs[1]; configs[2] under torchrun = weak scaling).
+"""Benchmarks of the hot path (BASELINE.json).  Default = the headline: 96^3 volumes/s of UNet (MONAI BasicUNet 1->3)
+forward + DiceCE + backward + AdamW, bf16, per-GPU batch 2 (configs[1]; configs[2] under torchrun = weak scaling).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --workload swin_unetr        # configs[3]: Swin-UNETR-48 (reference encoder), same step
+    python bench.py --workload sliding_window    # configs[4]: 512^3 sliding-window inference, roi 96^3, overlap 0.5
 
-Prints ONE JSON line on rank 0 (see DESIGN.md for the fields).  `--workload sliding_window` times the
-512^3 sliding-window inference loop instead (reported in DESIGN.md, not the headline line).
+Prints ONE JSON line on rank 0; `config.workload`, the FLOP / byte model, `roofline` (dominant kernel, measured with HIP
+events in this process) and `cpu_baseline` (the oracle on the host cores, bounded sample) all follow `--workload`.
 """
 from __future__ import annotations
 
@@ -23,12 +25,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic work of BasicUNet(32,32,64,128,256,32) 1->3, one 96^3 sample
-UNET_FWD_GFLOP_PER_VOL = 252.4
-UNET_FWDBWD_GFLOP_PER_VOL = 757.0
-UNET_FWDBWD_GB_PER_VOL_BF16 = 2.06
 MFMA_PEAK_BF16_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_F32_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
+
+# Algorithmic work per unit (one 96^3 sample = one "vol" for training, one
+# 512^3 volume for inference).  fwd+bwd = 3x forward FLOPs; fwd+bwd bytes = 3x forward bytes (X + 2 dY + dX + 2 W).
+WORK = {
+    "unet": {"gflop_per_vol": 757.0, "gb_per_vol_bf16": 2.06,
+             "metric": "96^3 vols/sec fwd+bwd (train)",
+             "name": "UNet base (MONAI BasicUNet 32-32-64-128-256-32) 1->{c}cls, {s}^3 patches, DiceCE + AdamW, per-GPU batch {b}"},
+    "swin_unetr": {"gflop_per_vol": 3 * 631.0, "gb_per_vol_bf16": 3 * 1.88,
+                   "metric": "96^3 vols/sec fwd+bwd (train), Swin-UNETR-48",
+                   "name": "Swin-UNETR 48-feat (reference encoder swin_nnformer: depths 2-2-2-2, heads 3-6-12-24, windows 6-6-6-3, "
+                           "patch 2 + UNETR decoder) 1->{c}cls, {s}^3 patches, DiceCE + AdamW, per-GPU batch {b}"},
+    "sliding_window": {"gflop_per_vol": 252.4e3, "gb_per_vol_bf16": 714.0,
+                       "metric": "512^3 sliding-window vols/sec",
+                       "name": "UNet base 1->{c}cls, {v}^3 volume, roi {s}^3, overlap 0.5, gaussian, {w} windows, sw_batch {b}"},
+}
+
+KERNEL_NAMES = {
+    "conv3d_k3_fwd/v3": "k3pp_kernel (conv3d k3 fwd + dgrad, bf16, 32-input-channel stages, 4x4x16 tiles, LDS-DMA ping-pong)",
+    "conv3d_k3_fwd/v0": "igemm_fwd_kernel<27,DIRECT,STORE,4,8,16,8> (conv3d k3 fwd + dgrad, 4x8x16 tiles)",
+    "conv3d_k3_fwd/v1": "igemm_fwd_kernel<27,DIRECT,STORE,4,4,8,4> (conv3d k3 fwd + dgrad, 4x4x8 tiles)",
+    "conv3d_k3_fwd/v2": "igemm_fwd_kernel<27,DIRECT,STORE,2,4,8,4> (conv3d k3 fwd + dgrad, 2x4x8 tiles)",
+    "conv3d_k3_wgrad": "k3wg_pp_kernel / igemm_wgrad_kernel (conv3d k3 weight gradient)",
+}
+
+
+def host_cores():
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return min(cores, 16)   # the GPU box grants one GPU's CPU share (16 cores); oversubscribing slows torch down
 
 
 def synth_batch(batch, size, n_cls, device, seed):
@@ -44,26 +75,27 @@ def synth_batch(batch, size, n_cls, device, seed):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(batch, size, n_cls, budget_s=25.0):
-    """The CPU oracle (torch fp32, all host cores) on the same synthetic step; bounded sample."""
-    from oracle.blocks import BasicUNet
+def cpu_baseline_train(workload, batch, size, n_cls, budget_s=25.0):
+    """The CPU oracle (torch fp32, host cores) on the same synthetic training step; bounded sample."""
     from oracle.losses import dice_ce_loss
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    cores = min(cores, 16)   # the GPU box grants one GPU's CPU share (16 cores); oversubscribing slows torch down
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    net = BasicUNet(1, n_cls)
+    if workload == "unet":
+        from oracle.blocks import BasicUNet
+        net = BasicUNet(1, n_cls)
+        what = "oracle/ BasicUNet"
+    else:
+        from oracle import swin as O
+        net = O.SwinUNETRCustom(O.SwinTransformerNNFormer((size,) * 3), 1, n_cls, 48, 2)
+        what = "oracle/ SwinUNETRCustom(SwinTransformerNNFormer 48)"
     opt = torch.optim.AdamW(net.parameters(), lr=4e-4, betas=(0.9, 0.95), eps=1e-6)
     x, y = synth_batch(batch, size, n_cls, "cpu", 13)
     times = []
     t_all = time.perf_counter()
     for i in range(4):
         t0 = time.perf_counter()
-        loss = dice_ce_loss(net(x), y)
+        loss = dice_ce_loss(net((x, None, None)), y)
         loss.backward()
         opt.step()
         opt.zero_grad()
@@ -74,49 +106,148 @@ def cpu_baseline(batch, size, n_cls, budget_s=25.0):
     med = sorted(steady)[len(steady) // 2]
     return {"value": round(batch / med, 4), "unit": "vol/s", "cores": cores, "kind": "port",
             "sample": f"{len(steady)} timed step(s) (after 1 warm-up) of the same B={batch} {size}^3 fwd+DiceCE+bwd+AdamW "
-                      f"step, oracle/ BasicUNet fp32 on torch-CPU, median {med:.2f} s/step"}
+                      f"step, {what} fp32 on torch-CPU, median {med:.2f} s/step"}
+
+
+def cpu_baseline_sw(size, n_cls, n_windows, sw_batch=4, budget_s=25.0):
+    """The oracle's window forward (+ its blend) on a bounded sample of the 512^3 job: >= 20 windows of 96^3, extrapolated
+    to the job's window count."""
+    from oracle.blocks import BasicUNet
+    from oracle.sliding_window import compute_importance_map
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = BasicUNet(1, n_cls).eval()
+    imp = compute_importance_map((size,) * 3, "gaussian", 0.125)
+    g = torch.Generator().manual_seed(13)
+    acc = torch.zeros(n_cls, size, size, size)
+    cnt = torch.zeros(n_cls, size, size, size)
+    done, t_all = 0, time.perf_counter()
+    with torch.no_grad():
+        net(torch.randn(1, 1, size, size, size, generator=g))       # warm-up
+        t0 = time.perf_counter()
+        while done < 20 or (time.perf_counter() - t_all < budget_s and done < 40):
+            seg = net(torch.randn(sw_batch, 1, size, size, size, generator=g))
+            for j in range(sw_batch):
+                acc += imp * seg[j]
+                cnt += imp
+            done += sw_batch
+        dt = time.perf_counter() - t0
+    per_win = dt / done
+    return {"value": round(1.0 / (per_win * n_windows), 6), "unit": "vol/s", "cores": cores, "kind": "port",
+            "sample": f"{done} windows of {size}^3 (forward of oracle/ BasicUNet fp32 on torch-CPU in batches of {sw_batch} + "
+                      f"weighted blend), {per_win:.3f} s/window, extrapolated to the {n_windows} windows of one volume"}
+
+
+def roofline_from_timer(summ, dtype, step_ms, instr_steps, prefer=None):
+    """dominant instrumented kernel (largest total time) -> the roofline object"""
+    if not summ:
+        return None
+    kid = prefer if prefer in summ else max(summ, key=lambda k: summ[k]["total_ms"])
+    k = summ[kid]
+    tf = k["flops"] / (k["total_ms"] * 1e-3) / 1e12
+    peak = MFMA_PEAK_BF16_TFLOPS if dtype == "bf16" else MFMA_PEAK_F32_TFLOPS
+    traffic = tshape = None
+    try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE x2 + WRITE_SIZE
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            ent = json.load(fh).get(kid)
+        if ent and dtype == "bf16":
+            traffic, tshape = ent["hbm_bytes_per_launch"], ent.get("shape")
+    except (OSError, ValueError):
+        pass
+    allk = [v for kk, v in summ.items() if kk.startswith("conv3d_k3_fwd")]
+    r = {"bound": "mfma", "kernel": KERNEL_NAMES.get(kid, kid), "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+         "frac": round(tf / peak, 4), "traffic": traffic, "traffic_shape": tshape, "launches": k["launches"],
+         "avg_ms": round(k["avg_ms"], 4), "flops_per_launch_avg": round(k["flops"] / k["launches"]),
+         "algorithmic_bytes_per_launch_avg": round(k["bytes"] / k["launches"]),
+         "share_of_step": round((k["total_ms"] / instr_steps) / step_ms, 3)}
+    if allk:
+        r["all_k3_variants_tflops"] = round(sum(v["flops"] for v in allk) / (sum(v["total_ms"] for v in allk) * 1e-3) / 1e12, 2)
+    w = summ.get("conv3d_k3_wgrad")
+    if w and kid != "conv3d_k3_wgrad":
+        r["wgrad_tflops"] = round(w["flops"] / (w["total_ms"] * 1e-3) / 1e12, 2)
+        r["wgrad_share_of_step"] = round((w["total_ms"] / instr_steps) / step_ms, 3)
+    return r
 
 
 def bench_sliding_window(args, dev, dtype, world, rank):
-    """512^3 sliding-window inference (roi 96^3, overlap 0.5, gaussian; 1000 windows) with the UNet in eval mode"""
-    from medicalsemseg_amd import parallel
-    from medicalsemseg_amd.engine.utils import sliding_window_inference
-    from medicalsemseg_amd.models.unet import UNet
+    """512^3 sliding-window inference (roi 96^3, overlap 0.5, gaussian; 1000 windows) with the UNet in eval mode.
+    N > 1: window batches dealt round-robin to the ranks, one all-gather of logits per step, every rank blends."""
+    from medicalsemseg_amd import hip
+    from medicalsemseg_amd.engine import utils as U
+    from medicalsemseg_amd.models.unet import LOGIT_LD, UNet
     net = UNet(1, args.classes, compute_dtype=dtype).to(dev).eval()
-    g = torch.Generator().manual_seed(13)
+    g = torch.Generator().manual_seed(13)            # the same volume on every rank (shard_ranks contract)
     vol = torch.randn(1, 1, args.sw_size, args.sw_size, args.sw_size, generator=g).to(dev)
     aff = torch.ones(1, 3, device=dev)
+    n_win = len(U.window_starts((args.sw_size,) * 3, (args.size,) * 3,
+                                U.get_scan_interval((args.sw_size,) * 3, (args.size,) * 3, 3, 0.5)))
 
     def run():
         with torch.no_grad():
-            return sliding_window_inference(vol, aff, (args.size,) * 3, args.sw_batch, net, overlap=0.5, mode="gaussian")
+            return U.sliding_window_inference(vol, aff, (args.size,) * 3, args.sw_batch, net, overlap=0.5, mode="gaussian",
+                                              shard_ranks=world > 1)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(max(args.warmup, 1)):
         out = run()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = run()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        value = args.steps / dt
+        w = WORK["sliding_window"]
+        nsteps = -(-n_win // (args.sw_batch * world))
+        res = {"metric": w["metric"] if args.sw_size == 512 else f"{args.sw_size}^3 sliding-window vols/sec",
+               "value": round(value, 4), "unit": "vol/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "launch": "hipGraph replay of the window forward",
+               "config": {"workload": w["name"].format(c=args.classes, v=args.sw_size, s=args.size, w=n_win, b=args.sw_batch),
+                          "parallelism": f"window batches round-robin over {world} rank(s)" + (
+                              ", one all-gather of logits per step" if world > 1 else ""),
+                          "windows_per_rank": [sum(1 for s in range(nsteps) for j in range(args.sw_batch)
+                                                   if (s * world + r) * args.sw_batch + j < n_win) for r in range(world)],
+                          "all_gather_bytes_per_rank_per_volume": (0 if world == 1 else
+                              nsteps * world * args.sw_batch * args.size ** 3 * LOGIT_LD * (2 if args.dtype == "bf16" else 4)),
+                          "out_mean": round(float(out.mean()), 5)}}
+        scale = (args.sw_size / 512.0) ** 3
+        res["model_tflops"] = round(value * w["gflop_per_vol"] * n_win / 1000.0 / 1e3, 2)
+        res["hbm_roofline_frac_algorithmic"] = round(value * w["gb_per_vol_bf16"] * scale / HBM_PEAK_GBS, 4)
+        # dominant kernel: instrumented eager window batches right after the timed region
+        win = torch.zeros(args.sw_batch, args.size, args.size, args.size, 1, dtype=dtype, device=dev)
+        hip.TIMER.records.clear()
+        hip.TIMER.enabled = True
+        nrep = 3
+        for _ in range(nrep):
+            net.infer_cl(win)
+        torch.cuda.synchronize()
+        hip.TIMER.enabled = False
+        batch_ms = dt / args.steps * 1e3 / nsteps
+        res["roofline"] = roofline_from_timer(hip.TIMER.summary(), args.dtype, batch_ms, nrep, "conv3d_k3_fwd/v3")
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_sw(args.size, args.classes, n_win)
+        print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if rank == 0:
-        print(json.dumps({"metric": f"{args.sw_size}^3 sliding-window vols/sec", "value": round(args.steps / dt, 4),
-                          "unit": "vol/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
-                          "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                          "config": {"workload": f"UNet base 1->{args.classes}, {args.sw_size}^3 volume, roi {args.size}^3, "
-                                                 f"overlap 0.5, gaussian, sw_batch {args.sw_batch}", "parallelism": f"windows/{world}",
-                                     "out_mean": round(float(out.mean()), 5)}}), flush=True)
-    if world > 1:
         torch.distributed.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--classes", type=int, default=3)
@@ -128,8 +259,12 @@ def main():
     ap.add_argument("--workload", default="unet", choices=["unet", "swin_unetr", "sliding_window"],
                     help="unet = the headline (BASELINE configs[1]); swin_unetr = configs[3]; sliding_window = configs[4]")
     ap.add_argument("--sw-size", type=int, default=512)
-    ap.add_argument("--sw-batch", type=int, default=8)   # windows per forward (1.48 / 1.64 / 1.51 vol/s at 4 / 8 / 16)
+    ap.add_argument("--sw-batch", type=int, default=8)   # windows per forward
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 3 if args.workload == "sliding_window" else 20
+    if args.warmup is None:
+        args.warmup = 1 if args.workload == "sliding_window" else 5
 
     from medicalsemseg_amd import hip, parallel
     from medicalsemseg_amd.losses import DiceCELoss
@@ -167,9 +302,9 @@ def main():
     crit = DiceCELoss(smooth_nr=1e-5, smooth_dr=1e-5)
     x, y = synth_batch(args.batch, args.size, args.classes, dev, 13 + rank)
 
-    # Data parallel: parallel.GradSync averages the flat gradient buffer over the ranks; with the UNet's two-phase
-    # backward the first (large) all-reduce runs under the tail of the backward.  --split-graph rehearses the same
-    # step structure on one GPU (no collective is issued on a single rank).
+    # Data parallel: parallel.GradSync averages the flat gradient buffer over the ranks; with a two-phase backward the
+    # first (large) all-reduce runs under the tail of the backward.  --split-graph rehearses the same step structure on
+    # one GPU (no collective is issued on a single rank).
     gsync = parallel.GradSync(opt, net)
     if args.split_graph and hasattr(net, "defer_backward_tail") and not os.environ.get("MSSEG_NO_GRAD_OVERLAP"):
         net.defer_backward_tail(True)
@@ -196,9 +331,9 @@ def main():
         loss = step()
     sync()
     # Replay the step from captured hipGraphs; the work per replay is exactly the eager step's.  Single GPU: ONE graph
-    # (forward + loss + backward + AdamW).  Multi-GPU (or --split-graph): graph A = forward + loss + backward, then
-    # the RCCL all-reduce of the flat gradient buffer as an ordinary eager call, then graph B = AdamW + zero_grad --
-    # the collective stays outside the graphs, the ~200 kernel launches of the step do not pay Python per launch.
+    # (forward + loss + backward + AdamW).  Multi-GPU (or --split-graph): graph A = forward + loss + backward head, the
+    # RCCL all-reduce of the finished gradient suffix as an ordinary eager call under graph A2 = backward tail, the
+    # all-reduce of the rest, then graph B = AdamW + zero_grad -- the collectives stay outside the graphs.
     graph = None
     graph_b = None
     graph_tail = None
@@ -273,7 +408,7 @@ def main():
         instr_steps = min(args.steps, 5)
         # per-kernel HIP-event timing needs eager launches: instrument a few extra steps right after the timed region
         hip.TIMER.enabled = True
-        for _ in range(min(args.steps, 5)):
+        for _ in range(instr_steps):
             step()
         sync()
         hip.TIMER.enabled = False
@@ -285,57 +420,31 @@ def main():
 
     vols = args.batch * args.steps * world
     value = vols / dt
+    w = WORK[args.workload]
     res = {
-        "metric": "96^3 vols/sec fwd+bwd (train)" if args.workload == "unet" else
-                  "96^3 vols/sec fwd+bwd (train), Swin-UNETR-48 (reference encoder, window 6/6/6/3)",
-        "value": round(value, 3), "unit": "vol/s", "n_gpus": world,
+        "metric": w["metric"], "value": round(value, 3), "unit": "vol/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "launch": ("hipGraph replay" if graph_b is None else
                    "hipGraph replay (fwd+bwd head | all-reduce under bwd tail | all-reduce | optimiser)" if graph_tail is not None
                    else "hipGraph replay (fwd+bwd | all-reduce | optimiser)")
                   if graph is not None else "eager",
-        "config": {"workload": f"UNet base (MONAI BasicUNet 32-32-64-128-256-32) 1->{args.classes}cls, {args.size}^3 "
-                               f"patches, DiceCE + AdamW, per-GPU batch {args.batch}", "global_batch": args.batch * world,
-                   "parallelism": f"dp{world}", "final_loss": round(loss_v, 5)},
+        "config": {"workload": w["name"].format(c=args.classes, s=args.size, b=args.batch), "global_batch": args.batch * world,
+                   "parallelism": f"dp{world}", "final_loss": round(loss_v, 5),
+                   "grad_sync": ("none (single rank)" if world == 1 else
+                                 f"flat fp32 gradient buffer, {opt.flat_grad.numel() * 4} bytes per step, " +
+                                 ("two all-reduces, the first under the backward tail" if gsync.overlapped else "one all-reduce"))},
     }
     if rank == 0:
-        summ = hip.TIMER.summary()
-        # dominant kernel = the conv3d k3 forward / input-gradient kernel of the 32-channel stages (the 96^3 and 48^3
-        # levels): v3 = LDS-DMA ping-pong kernel (conv3d_k3_pp.hip); falls back to the generic big-tile kernel (v0)
-        kid = "conv3d_k3_fwd/v3" if "conv3d_k3_fwd/v3" in summ else "conv3d_k3_fwd/v0"
-        k = summ.get(kid)
-        if k:
-            tf = k["flops"] / (k["total_ms"] * 1e-3) / 1e12
-            peak = MFMA_PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-            allk = [v for kk, v in summ.items() if kk.startswith("conv3d_k3_fwd")]
-            name = ("k3pp_kernel<STATS> (conv3d k3 fwd + dgrad, bf16, 32-channel stages, 4x4x16 tiles, LDS-DMA ping-pong)"
-                    if kid.endswith("v3") else
-                    "igemm_fwd_kernel<27,DIRECT,STORE,4,8,16,8,NT=2> (conv3d k3 fwd + dgrad, 4x8x16 tiles)")
-            traffic = None
-            try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE x2 + WRITE_SIZE
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")) as fh:
-                    tj = json.load(fh)
-                ent = tj.get(kid)
-                if ent and args.dtype == "bf16" and args.size == ent.get("size") and args.batch == ent.get("batch"):
-                    traffic = ent["hbm_bytes_per_launch"]
-            except (OSError, ValueError):
-                pass
-            res["roofline"] = {"bound": "mfma", "kernel": name,
-                               "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                               "traffic": traffic, "traffic_shape": "32->32 @96^3 B=2 launch (97.8 GFLOP, 226.5 MB algorithmic)" if traffic else None,
-                               "launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
-                               "flops_per_launch_avg": round(k["flops"] / k["launches"]),
-                               "share_of_step": round((k["total_ms"] / instr_steps) / (dt * 1e3 / args.steps), 3),
-                               "all_k3_variants_tflops": round(sum(v["flops"] for v in allk) / (sum(v["total_ms"] for v in allk) * 1e-3) / 1e12, 2)}
-            w = summ.get("conv3d_k3_wgrad")
-            if w:
-                res["roofline"]["wgrad_tflops"] = round(w["flops"] / (w["total_ms"] * 1e-3) / 1e12, 2)
-                res["roofline"]["wgrad_share_of_step"] = round((w["total_ms"] / instr_steps) / (dt * 1e3 / args.steps), 3)
-        res["model_tflops"] = round(value / world * UNET_FWDBWD_GFLOP_PER_VOL / 1e3, 2)
-        res["hbm_roofline_frac_algorithmic"] = round(value / world * UNET_FWDBWD_GB_PER_VOL_BF16 / HBM_PEAK_GBS, 4)
+        scale = (args.size / 96.0) ** 3
+        step_ms = dt * 1e3 / args.steps
+        res["roofline"] = roofline_from_timer(hip.TIMER.summary(), args.dtype, step_ms, instr_steps,
+                                              "conv3d_k3_fwd/v3" if args.workload == "unet" else None)
+        res["model_tflops"] = round(value / world * w["gflop_per_vol"] * scale / 1e3, 2)
+        res["hbm_roofline_frac_algorithmic"] = round(value / world * w["gb_per_vol_bf16"] * scale *
+                                                     (1 if args.dtype == "bf16" else 2) / HBM_PEAK_GBS, 4)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.batch, args.size, args.classes)
+            res["cpu_baseline"] = cpu_baseline_train(args.workload, args.batch, args.size, args.classes)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -156,6 +156,9 @@ int msseg_deconv_k2s2_bwd_data_inbwd(const void* dy, long long lddy, const void*
  * `accumulate` != 0 adds into dw instead of overwriting.
  * ------------------------------------------------------------------------------------------- */
 size_t msseg_wgrad_workspace_bytes(int M, int T, int K);
+/* which kernel msseg_conv3d_k3_wgrad selects for dense (ld == channels), aligned tensors of this shape:
+ * 3 = LDS-DMA ping-pong kernel (conv3d_k3_wgrad_pp.hip), 0 = generic igemm_wgrad kernel (tests assert the selection). */
+int msseg_conv3d_k3_wgrad_kernel(int N, int D, int H, int W, int Cin, int Cout, int dtype);
 int msseg_conv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw,
                           int N, int D, int H, int W, int Cin, int Cout, int accumulate,
                           void* workspace, size_t workspace_bytes, int dtype, msseg_stream_t stream);
@@ -313,6 +316,19 @@ int msseg_sw_blend(const void* win, long long ld, int dtype, const float* imp, f
 int msseg_sw_gather(const float* vol, void* win, int dtype, int C, int VD, int VH, int VW, int RD, int RH, int RW,
                     int z0, int y0, int x0, float cval, msseg_stream_t stream);
 int msseg_sw_normalize(float* out, const float* cnt, int C, long long V, msseg_stream_t stream);
+/* Batched forms (one launch per window batch; the reference's loop body engine/utils.py:120-148 for `sw_batch_size`
+ * windows at once).  table: device int32 [nwin][4] = (sample b, z0, y0, x0); b < 0 = unused slot.
+ * gather: win[j] = window j of vol[b] (fp32 [B][C][VD][VH][VW], sample stride vol_bstride elements), `cval` outside;
+ *         win layout NCDHW [nwin][C][roi] when ldw == 0, channels-last [nwin][roi][ldw] otherwise.
+ * blend : out[b][c][vol] += imp * win[j][c], cnt[b][vol] += imp for every window of the table, each output voxel
+ *         accumulated in table order with the reference's roundings (bit-identical to nwin sequential msseg_sw_blend
+ *         calls); windows of one batch may overlap.  nwin <= 256, C <= 16. */
+int msseg_sw_gather_batch(const float* vol, long long vol_bstride, void* win, long long ldw, int dtype, const int* table,
+                          int nwin, int C, int VD, int VH, int VW, int RD, int RH, int RW, float cval,
+                          msseg_stream_t stream);
+int msseg_sw_blend_batch(const void* win, long long ldw, int dtype, const float* imp, float* out, long long out_bstride,
+                         float* cnt, long long cnt_bstride, const int* table, int nwin, int C, int VD, int VH, int VW,
+                         int RD, int RH, int RW, msseg_stream_t stream);
 
 #ifdef __cplusplus
 }

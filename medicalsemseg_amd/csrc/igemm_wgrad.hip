@@ -548,6 +548,14 @@ size_t msseg_wgrad_workspace_bytes(int M, int T, int K) {
     return per_slot * slots * (T == 1 ? 4 : 1);
 }
 
+int msseg_conv3d_k3_wgrad_kernel(int N, int D, int H, int W, int Cin, int Cout, int dtype) {
+    if (dtype != MSSEG_BF16) return 0;
+    K3WgParams pp{};
+    pp.pten = (const void*)256; pp.ldp = Cout; pp.qten = (const void*)256; pp.ldq = Cin;
+    pp.N = N; pp.D = D; pp.H = H; pp.W = W; pp.M = Cout; pp.K = Cin; pp.kblks = ceil_div(Cin, 32);
+    return msseg_k3wg_pp_eligible(pp) ? 3 : 0;
+}
+
 int msseg_conv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, int N, int D, int H,
                           int W, int Cin, int Cout, int accumulate, void* workspace, size_t workspace_bytes, int dtype,
                           msseg_stream_t stream) {

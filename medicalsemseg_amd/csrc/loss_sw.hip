@@ -215,6 +215,108 @@ __global__ void sw_gather_kernel(const float* __restrict__ vol, T* __restrict__ 
     }
 }
 
+
+// ---- batched forms: one launch per window batch, window starts in a device-resident table ----------------
+// table[j] = (b, z0, y0, x0); b < 0 marks an unused slot (short last batch).
+template <typename T>
+__global__ void sw_gather_batch_kernel(const float* __restrict__ vol, long long vol_bstride, T* __restrict__ win,
+                                       long long ldw, const int* __restrict__ table, int nwin, int C, int VD, int VH,
+                                       int VW, int RD, int RH, int RW, float cval) {
+    const long long R = (long long)RD * RH * RW, V = (long long)VD * VH * VW;
+    const int j = blockIdx.y;
+    const int b = table[j * 4 + 0];
+    if (b < 0) return;
+    const int z0 = table[j * 4 + 1], y0 = table[j * 4 + 2], x0 = table[j * 4 + 3];
+    const float* vb = vol + (long long)b * vol_bstride;
+    for (long long ri = blockIdx.x * 256LL + threadIdx.x; ri < R; ri += (long long)gridDim.x * 256) {
+        const int rx = (int)(ri % RW), ry = (int)((ri / RW) % RH), rz = (int)(ri / ((long long)RW * RH));
+        const int z = z0 + rz, y = y0 + ry, x = x0 + rx;
+        const bool in = (unsigned)z < (unsigned)VD && (unsigned)y < (unsigned)VH && (unsigned)x < (unsigned)VW;
+        const long long v = ((long long)z * VH + y) * VW + x;
+        for (int c = 0; c < C; ++c) {
+            const float val = in ? vb[c * V + v] : cval;
+            if (ldw > 0) DT<T>::st(win + ((long long)j * R + ri) * ldw + c, val);
+            else DT<T>::st(win + ((long long)j * C + c) * R + ri, val);
+        }
+    }
+}
+
+// Every output voxel touched by the batch is owned by exactly one thread -- the thread of the FIRST window (in table
+// order) that covers it -- which then adds the contributions of all windows of the batch covering that voxel, in
+// table order, with the reference's two roundings per window (mul, then add): the same fp32 sequence as
+// `out[idx] += imp * seg` executed window after window (/root/reference/engine/utils.py:146-148).
+template <typename T, int CMAX>
+__global__ __launch_bounds__(256) void sw_blend_batch_kernel(const T* __restrict__ win, long long ldw,
+                                                             const float* __restrict__ imp, float* __restrict__ out,
+                                                             long long out_bstride, float* __restrict__ cnt,
+                                                             long long cnt_bstride, const int* __restrict__ table,
+                                                             int nwin, int C, int VD, int VH, int VW, int RD, int RH,
+                                                             int RW) {
+#pragma clang fp contract(off)
+    __shared__ int tab[256 * 4];
+    for (int i = threadIdx.x; i < nwin * 4; i += 256) tab[i] = table[i];
+    __syncthreads();
+    const long long R = (long long)RD * RH * RW, V = (long long)VD * VH * VW;
+    const int j = blockIdx.y;
+    const int b = tab[j * 4 + 0];
+    if (b < 0) return;
+    const int z0 = tab[j * 4 + 1], y0 = tab[j * 4 + 2], x0 = tab[j * 4 + 3];
+    for (long long ri = blockIdx.x * 256LL + threadIdx.x; ri < R; ri += (long long)gridDim.x * 256) {
+        const int rx = (int)(ri % RW), ry = (int)((ri / RW) % RH), rz = (int)(ri / ((long long)RW * RH));
+        const int z = z0 + rz, y = y0 + ry, x = x0 + rx;
+        bool owner = true;
+        for (int k = 0; k < j; ++k) {
+            if (tab[k * 4] != b) continue;
+            const unsigned dz = (unsigned)(z - tab[k * 4 + 1]), dy = (unsigned)(y - tab[k * 4 + 2]),
+                           dx = (unsigned)(x - tab[k * 4 + 3]);
+            if (dz < (unsigned)RD && dy < (unsigned)RH && dx < (unsigned)RW) { owner = false; break; }
+        }
+        if (!owner) continue;
+        const long long v = ((long long)z * VH + y) * VW + x;
+        float* ob = out + (long long)b * out_bstride;
+        float* cb = cnt + (long long)b * cnt_bstride;
+        float o[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) o[c] = c < C ? ob[c * V + v] : 0.f;
+        float cv = cb[v];
+        for (int k = j; k < nwin; ++k) {
+            if (tab[k * 4] != b) continue;
+            const unsigned dz = (unsigned)(z - tab[k * 4 + 1]), dy = (unsigned)(y - tab[k * 4 + 2]),
+                           dx = (unsigned)(x - tab[k * 4 + 3]);
+            if (dz >= (unsigned)RD || dy >= (unsigned)RH || dx >= (unsigned)RW) continue;
+            const long long pi = ((long long)dz * RH + dy) * RW + dx;
+            const float w = imp[pi];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                if (c < C) {
+                    const float val = ldw > 0 ? DT<T>::ld(win + ((long long)k * R + pi) * ldw + c)
+                                              : DT<T>::ld(win + ((long long)k * C + c) * R + pi);
+                    const float prod = w * val;
+                    o[c] = o[c] + prod;
+                }
+            }
+            cv = cv + w;
+        }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) ob[c * V + v] = o[c];
+        cb[v] = cv;
+    }
+}
+
+template <typename T, int CMAX>
+int launch_blend_batch(const void* win, long long ldw, const float* imp, float* out, long long obs, float* cnt,
+                              long long cbs, const int* table, int nwin, int C, int VD, int VH, int VW, int RD, int RH,
+                              int RW, hipStream_t st) {
+    const long long R = (long long)RD * RH * RW;
+    long long gx = ceil_div_ll(R, 256);
+    if (gx > 65535) gx = 65535;
+    hipLaunchKernelGGL((sw_blend_batch_kernel<T, CMAX>), dim3((unsigned)gx, nwin), dim3(256), 0, st, (const T*)win, ldw,
+                       imp, out, obs, cnt, cbs, table, nwin, C, VD, VH, VW, RD, RH, RW);
+    MSSEG_CHECK_LAUNCH("sw_blend_batch");
+    return MSSEG_OK;
+}
+
 inline int grid_for(long long total, int per_thread = 4) {
     long long b = ceil_div_ll(total, 256LL * per_thread);
     const long long cap = (long long)msseg_num_cus() * 16;
@@ -333,6 +435,38 @@ int msseg_sw_gather(const float* vol, void* win, int dtype, int C, int VD, int V
                            VH, VW, RD, RH, RW, z0, y0, x0, cval);
     else MSSEG_FAIL(MSSEG_EINVAL, "sw_gather: bad dtype");
     MSSEG_CHECK_LAUNCH("sw_gather");
+    return MSSEG_OK;
+}
+
+int msseg_sw_blend_batch(const void* win, long long ldw, int dtype, const float* imp, float* out, long long out_bstride,
+                         float* cnt, long long cnt_bstride, const int* table, int nwin, int C, int VD, int VH, int VW,
+                         int RD, int RH, int RW, msseg_stream_t stream) {
+    if (!win || !imp || !out || !cnt || !table) MSSEG_FAIL(MSSEG_EINVAL, "sw_blend_batch: null pointer");
+    if (nwin < 1 || nwin > 256) MSSEG_FAIL(MSSEG_EINVAL, "sw_blend_batch: 1 <= nwin <= 256 windows per launch (got %d)", nwin);
+    if (C < 1 || C > 16) MSSEG_FAIL(MSSEG_EINVAL, "sw_blend_batch: 1 <= C <= 16 classes");
+    if (RD < 1 || RH < 1 || RW < 1 || RD > VD || RH > VH || RW > VW)
+        MSSEG_FAIL(MSSEG_EINVAL, "sw_blend_batch: roi (%d,%d,%d) does not fit the volume (%d,%d,%d)", RD, RH, RW, VD, VH, VW);
+    DISPATCH_TC(dtype, C, launch_blend_batch, win, ldw, imp, out, out_bstride, cnt, cnt_bstride, table, nwin, C, VD, VH,
+                VW, RD, RH, RW, (hipStream_t)stream);
+}
+
+int msseg_sw_gather_batch(const float* vol, long long vol_bstride, void* win, long long ldw, int dtype, const int* table,
+                          int nwin, int C, int VD, int VH, int VW, int RD, int RH, int RW, float cval,
+                          msseg_stream_t stream) {
+    if (!vol || !win || !table) MSSEG_FAIL(MSSEG_EINVAL, "sw_gather_batch: null pointer");
+    if (nwin < 1 || nwin > 65535 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "sw_gather_batch: bad window / channel count");
+    if (ldw != 0 && ldw < C) MSSEG_FAIL(MSSEG_EINVAL, "sw_gather_batch: ldw smaller than the channel count");
+    const long long R = (long long)RD * RH * RW;
+    long long gx = ceil_div_ll(R, 256LL * 2);
+    if (gx > 65535) gx = 65535;
+    if (dtype == MSSEG_F32)
+        hipLaunchKernelGGL(sw_gather_batch_kernel<float>, dim3((unsigned)gx, nwin), dim3(256), 0, (hipStream_t)stream, vol,
+                           vol_bstride, (float*)win, ldw, table, nwin, C, VD, VH, VW, RD, RH, RW, cval);
+    else if (dtype == MSSEG_BF16)
+        hipLaunchKernelGGL(sw_gather_batch_kernel<bf16_t>, dim3((unsigned)gx, nwin), dim3(256), 0, (hipStream_t)stream,
+                           vol, vol_bstride, (bf16_t*)win, ldw, table, nwin, C, VD, VH, VW, RD, RH, RW, cval);
+    else MSSEG_FAIL(MSSEG_EINVAL, "sw_gather_batch: bad dtype");
+    MSSEG_CHECK_LAUNCH("sw_gather_batch");
     return MSSEG_OK;
 }
 

@@ -13,11 +13,14 @@ from ..utils import misc
 
 
 def _metric_update(metric_logger, criterion, outputs, labels, n_cls):
-    hard = getattr(criterion, "last", {}).get("hard") if hasattr(criterion, "last") else None
+    # by-products of the fused DiceCE pass are used only when they were produced from THESE logits (a validation call or
+    # another cached graph may have run the criterion in between)
+    last = getattr(criterion, "last", None) or {}
+    hard = last.get("hard") if last.get("of") == (outputs.data_ptr(), tuple(outputs.shape)) else None
     custom = getattr(criterion, "hard_dice", None)   # injection point (tests drive the loop with the CPU oracle)
     if custom is not None:
         scores, not_nans = custom(outputs.detach(), labels)
-    elif hard is not None and hard.shape[0] == outputs.shape[0]:
+    elif hard is not None:
         scores, not_nans = L.dice_from_counts(hard)
     else:
         scores, not_nans = L.dice_metric(outputs.detach(), labels)
@@ -43,7 +46,8 @@ class _GraphedFwdBwd:
 
     @classmethod
     def get(cls, model, criterion, optimizer, inputs, labels):
-        key = (id(model), id(criterion), tuple(inputs.shape), inputs.dtype, tuple(labels.shape), labels.dtype, inputs.device)
+        key = (id(model), id(criterion), tuple(inputs.shape), inputs.dtype, tuple(labels.shape), labels.dtype, inputs.device,
+               optimizer.flat_grad.data_ptr(), optimizer.flat_param.data_ptr())   # a new FlatAdamW re-points p.data / p.grad
         g = cls._cache.get(key)
         if g is None or g.model() is not model:
             g = cls._cache[key] = cls(model, criterion, optimizer, inputs, labels)
@@ -71,6 +75,10 @@ class _GraphedFwdBwd:
             self.out = model((self.x, None, None))
             self.loss = criterion(self.out, self.y)
             self.loss.backward()
+        # the criterion's by-products (hard-Dice counts of THIS graph's static logits): a replay does not run
+        # _DiceCEFn.forward in Python, so they are re-bound after every replay
+        self.last = dict(getattr(criterion, "last", {}))
+        self.criterion = weakref.ref(criterion)
         # two-phase backward (parallel.GradSync): the tail of the backward is its own graph, so the all-reduce of the
         # gradients the head finished can be started between the two replays
         self.graph_tail = None
@@ -87,6 +95,9 @@ class _GraphedFwdBwd:
             if between is not None:
                 between()
             self.graph_tail.replay()
+        crit = self.criterion()
+        if crit is not None and hasattr(crit, "last"):
+            crit.last.update(self.last)
         return self.out, self.loss
 
 

@@ -6,9 +6,10 @@ function that feeds ``(window, centers, affine)`` tuples to the predictor): cons
 Gaussian (sigma = 0.125 * roi) or constant importance map, blend of raw LOGITS ``out += w * logit; cnt += w``,
 ``out / cnt``, crop of the padding.  Differences, all result-preserving: the window gather, blend and
 normalise are HIP kernels (``msseg_sw_gather/_blend/_normalize``); the count map has one channel instead of
-``classes`` identical ones; under ``torch.distributed`` the windows are sharded across ranks and their logits
-exchanged with ONE all-gather, after which every rank blends all windows in the reference order (bit-identical
-to the single-GPU result).
+``classes`` identical ones; under ``torch.distributed`` the accumulators are updated batch by batch (memory O(volume), like the reference); with
+``shard_ranks=True`` window batches are dealt round-robin to the ranks and each step's logits are exchanged with one
+all-gather, after which every rank blends the step's windows in the reference order (bit-identical to the single-GPU
+result).
 """
 from __future__ import annotations
 
@@ -100,47 +101,52 @@ def importance_map(patch_size: Sequence[int], mode="constant", sigma_scale=0.125
     return imp.to(device) if device is not None else imp
 
 
-class _GraphedPredictor:
-    """Replays `predictor((win, None, None))` on a static window batch from a captured hipGraph (models that declare
-    `graph_safe`: static shapes, no host synchronisation, no autograd).  A window batch is ~70 kernel launches of
-    20-100 us each: issued from Python they are launch-bound.  The captured graph starts with the batched weight
+class _GraphedInfer:
+    """`seg = predictor.infer_cl(win)` on a static batch of channels-last windows, replayed from a captured hipGraph
+    (models that declare `graph_safe` -- static shapes, no host synchronisation -- and offer `infer_cl`: channels-last
+    in, channels-last logits out, no layout passes, nothing retained).  A window batch is ~70 launches of 20-500 us;
+    issued from Python the small ones are launch-bound.  The captured graph starts with the batched weight
     re-packing, so a replay always sees the current parameters."""
 
     _cache = {}
 
     @classmethod
-    def get(cls, predictor, win: torch.Tensor):
-        key = (id(predictor), tuple(win.shape), win.dtype, win.device)
+    def get(cls, predictor, nb, cin, roi, dev):
+        key = (id(predictor), nb, cin, tuple(roi), dev)
         g = cls._cache.get(key)
         if g is None or g.predictor() is not predictor:
-            g = cls._cache[key] = cls(predictor, win)
+            g = cls._cache[key] = cls(predictor, nb, cin, roi, dev)
         return g
 
-    def __init__(self, predictor, win: torch.Tensor):
+    def __init__(self, predictor, nb, cin, roi, dev):
         import weakref
         from .. import layers
         self.predictor = weakref.ref(predictor)
-        self.win = torch.zeros_like(win)
-        side = torch.cuda.Stream(device=win.device)
+        self.win = torch.zeros(nb, *roi, cin, dtype=predictor.compute_dtype, device=dev)
+        side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            predictor((self.win, None, None))
+            predictor.infer_cl(self.win)    # warm-up: packed-weight images, workspaces
         torch.cuda.current_stream().wait_stream(side)
         layers.PACK_REGISTRY.prepare()
         layers.bump_weights_epoch()   # the capture then starts with the batched weight re-packing
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = predictor((self.win, None, None))
+            self.seg = predictor.infer_cl(self.win)
 
     def __call__(self):
         self.graph.replay()
-        return self.out
+        return self.seg
 
 
 def sliding_window_inference(inputs: torch.Tensor, affine, roi_size, sw_batch_size: int, predictor: Callable,
                              overlap: float = 0.25, mode: str = "constant", sigma_scale=0.125,
                              padding_mode: str = "constant", cval: float = 0.0, sw_device=None, device=None,
-                             *args, **kwargs) -> torch.Tensor:
+                             *args, shard_ranks: bool = False, **kwargs) -> torch.Tensor:
+    """`shard_ranks=True` (opt-in; every rank must pass the SAME `inputs`, in lock-step): window batches are dealt
+    round-robin to the ranks, each step's logits are exchanged with one all-gather and blended by every rank in the
+    single-rank order, so all ranks return the bit-identical single-rank result.  Default: every rank works on its own
+    volume, as the reference does (validation files are partitioned per rank, data/dataset_builder.py:455-464)."""
     if inputs.dim() != 5:
         raise ValueError("expects NCDHW volumes")
     if overlap < 0 or overlap >= 1:
@@ -161,55 +167,83 @@ def sliding_window_inference(inputs: torch.Tensor, affine, roi_size, sw_batch_si
     starts = window_starts(image_size, roi, interval)
     num_win = len(starts)
     total = num_win * B
+    nb = int(sw_batch_size)
     imp = importance_map(tuple(min(r, i) for r, i in zip(roi, image_size)), mode, sigma_scale, dev)
     vol = inputs.float().contiguous()
+    ws, rk = (parallel.world_size(), parallel.rank()) if shard_ranks else (1, 0)
 
-    ws, rk = parallel.world_size(), parallel.rank()
-    lo, hi = parallel.shard_windows(total, ws, rk)
-    per_rank = -(-total // ws)
-    my_logits = None
-    # graph replay of the window forward: models that ignore (centers, affine) and declare themselves graph-safe
-    graphed = None
-    if (getattr(predictor, "graph_safe", False) and not torch.is_grad_enabled() and not args and not kwargs
-            and not os.environ.get("MSSEG_NO_SW_GRAPH") and hi - lo >= sw_batch_size):
-        graphed = _GraphedPredictor.get(predictor, torch.empty(sw_batch_size, Cin, *roi, dtype=torch.float32, device=dev))
-    for g in range(lo, hi, sw_batch_size):
-        idxs = list(range(g, min(g + sw_batch_size, hi)))
-        if graphed is not None:
-            win = graphed.win   # a short last batch keeps the previous batch's windows in the unused slots
-        else:
-            win = torch.empty(len(idxs), Cin, *roi, dtype=torch.float32, device=dev)
-        centers = []
-        for j, idx in enumerate(idxs):
-            b, st = idx // num_win, starts[idx % num_win]
-            hip.sw_gather(vol[b], win[j], tuple(st[d] - pad_lo[d] for d in range(3)), cval)
-            centers.append([(st[d] + roi[d] - roi[d] // 2) / image_size[d] for d in range(3)])
-        if graphed is not None:
-            seg = graphed()[:len(idxs)]
-        else:
-            centers = torch.tensor(centers, dtype=torch.float32, device=dev)
-            if sw_batch_size == 1:
-                centers = centers.unsqueeze(0)  # reference quirk (engine/utils.py:131-132)
-            seg = predictor((win, centers, affine), *args, **kwargs)
-        if my_logits is None:
-            ncls = seg.shape[1]
-            my_logits = torch.zeros(per_rank, ncls, *roi, dtype=torch.float32, device=dev)
-        my_logits[g - lo:g - lo + len(idxs)] = seg.float()
-    if my_logits is None:
-        raise RuntimeError("a rank received no window")
-    if ws > 1:
-        gathered = torch.empty(ws * per_rank, *my_logits.shape[1:], dtype=torch.float32, device=dev)
-        torch.distributed.all_gather_into_tensor(gathered, my_logits)
+    # all window starts as (b, z0, y0, x0) rows, padded with unused slots to whole steps of ws * nb windows
+    nsteps = -(-total // (nb * ws))
+    rows_h = torch.full((nsteps * ws * nb, 4), -1, dtype=torch.int32)
+    st = torch.tensor(starts, dtype=torch.int32)
+    rows_h[:total, 0] = torch.arange(total, dtype=torch.int32) // num_win
+    rows_h[:total, 1:] = st.repeat(B, 1)
+    rows_gather = rows_h.clone()
+    rows_gather[:total, 1:] -= torch.tensor(pad_lo, dtype=torch.int32)    # gather reads the unpadded volume
+    rows_blend = rows_h.to(dev)
+    rows_gather = rows_gather.to(dev)
+
+    fast = (getattr(predictor, "graph_safe", False) and hasattr(predictor, "infer_cl") and not torch.is_grad_enabled()
+            and not args and not kwargs and not os.environ.get("MSSEG_NO_SW_GRAPH"))
+    out = cnt = gathered = None
+
+    def accumulators(ncls):
+        return (torch.zeros(B, ncls, *image_size, dtype=torch.float32, device=dev),
+                torch.zeros(B, *image_size, dtype=torch.float32, device=dev))
+
+    if fast:
+        # gather -> graph replay of the forward -> [all-gather] -> blend, per step; the accumulators are updated step by
+        # step (memory O(volume), as the reference), windows and logits never leave the channels-last compute dtype
+        g = _GraphedInfer.get(predictor, nb, Cin, roi, dev)
+        out, cnt = accumulators(predictor.out_channels)
+        for i in range(nsteps):
+            g0 = (i * ws + rk) * nb                       # this rank's batch of the step (all slots unused: idle replay)
+            hip.sw_gather_batch(vol, g.win, rows_gather[g0:g0 + nb], nb, cval, channels_last_ld=Cin)
+            seg = g()
+            if ws == 1:
+                hip.sw_blend_batch(seg, imp, out, cnt, rows_blend[g0:g0 + nb], nb, channels_last_ld=seg.shape[-1])
+                continue
+            if gathered is None:
+                gathered = torch.empty((ws * nb,) + tuple(seg.shape[1:]), dtype=seg.dtype, device=dev)
+            torch.distributed.all_gather_into_tensor(gathered, seg)
+            hip.sw_blend_batch(gathered, imp, out, cnt, rows_blend[i * ws * nb:(i + 1) * ws * nb], ws * nb,
+                               channels_last_ld=seg.shape[-1])
     else:
-        gathered = my_logits
-    ncls = gathered.shape[1]
-    out = torch.zeros(B, ncls, *image_size, dtype=torch.float32, device=dev)
-    cnt = torch.zeros(B, *image_size, dtype=torch.float32, device=dev)
-    for r in range(ws):
-        rlo, rhi = parallel.shard_windows(total, ws, r)
-        for idx in range(rlo, rhi):
-            b, st = idx // num_win, starts[idx % num_win]
-            hip.sw_blend(gathered[r * per_rank + idx - rlo], imp, out[b], cnt[b], st)
+        win = None
+        ncls = int(getattr(predictor, "out_channels", 0) or 0)
+        for i in range(nsteps):
+            g0 = (i * ws + rk) * nb                       # this rank's batch of the step
+            idxs = [g for g in range(g0, g0 + nb) if g < total]
+            seg = None
+            if idxs:
+                centers = torch.tensor([[(starts[g % num_win][d] + roi[d] - roi[d] // 2) / image_size[d] for d in range(3)]
+                                        for g in idxs], dtype=torch.float32, device=dev)
+                if sw_batch_size == 1:
+                    centers = centers.unsqueeze(0)  # reference quirk (engine/utils.py:131-132)
+                if win is None:
+                    win = torch.zeros(nb, Cin, *roi, dtype=torch.float32, device=dev)
+                hip.sw_gather_batch(vol, win, rows_gather[g0:g0 + nb], nb, cval)
+                seg = predictor((win[:len(idxs)], centers, affine), *args, **kwargs)
+                if seg.dtype not in (torch.float32, torch.bfloat16):
+                    seg = seg.float()
+                ncls = seg.shape[1]
+            if out is None:
+                if ws > 1:   # a rank without a window in step 0 (fewer windows than ranks) learns the class count here
+                    t = torch.tensor([ncls], dtype=torch.int64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    ncls = int(t.item())
+                out, cnt = accumulators(ncls)
+            if ws == 1:
+                hip.sw_blend_batch(seg.contiguous(), imp, out, cnt, rows_blend[g0:g0 + nb], len(idxs))
+                continue
+            # sharded: one all-gather per step, then every rank blends the step's ws * nb windows in global order
+            mine = torch.zeros(nb, ncls, *roi, dtype=torch.float32, device=dev)
+            if seg is not None:
+                mine[:len(idxs)] = seg.float()
+            if gathered is None:
+                gathered = torch.empty(ws * nb, ncls, *roi, dtype=torch.float32, device=dev)
+            torch.distributed.all_gather_into_tensor(gathered, mine)
+            hip.sw_blend_batch(gathered, imp, out, cnt, rows_blend[i * ws * nb:(i + 1) * ws * nb], ws * nb)
     for b in range(B):
         hip.sw_normalize(out[b], cnt[b])
     sl = [slice(None), slice(None)] + [slice(pad_lo[d], pad_lo[d] + image_size_[d]) for d in range(3)]

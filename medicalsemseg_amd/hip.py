@@ -63,6 +63,7 @@ SIGNATURES = {
     "msseg_deconv_k2s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_deconv_k2s2_bwd_data": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_wgrad_workspace_bytes": ([_i, _i, _i], _sz),
+    "msseg_conv3d_k3_wgrad_kernel": ([_i, _i, _i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_wgrad": ([_vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_k1_wgrad": ([_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_gather_wgrad": ([_vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "msseg_sw_blend": ([_vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_sw_normalize": ([_vp, _vp, _i, _ll, _vp], _i),
     "msseg_sw_gather": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "msseg_sw_gather_batch": ([_vp, _ll, _vp, _ll, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "msseg_sw_blend_batch": ([_vp, _ll, _i, _vp, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
 }
 
 
@@ -445,13 +448,17 @@ def deconv_k2s2_bwd_data(dy, wp, dx, cin, cout):
 # weight gradients
 # --------------------------------------------------------------------------------------------
 _ws_cache = {}
+_ws_retired = []   # superseded workspaces: captured hipGraphs may still launch kernels against them, so they are never freed
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (stable address => hipGraph friendly)."""
+    """Grow-only scratch buffer per device.  A larger request allocates a new buffer; the old one is retired, not
+    released, because graphs captured earlier keep its address baked into their kernel arguments."""
     key = (device.index if device.index is not None else torch.cuda.current_device())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)
         buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
@@ -714,6 +721,32 @@ def sw_gather(vol, win, start, cval=0.0):
     _ck(lib().msseg_sw_gather(_p(vol), _p(win), dt(win), Cc, VD, VH, VW, RD, RH, RW, int(start[0]), int(start[1]),
                               int(start[2]), float(cval), _stream()), "sw_gather")
     return win
+
+
+def sw_gather_batch(vol, win, table, nwin, cval=0.0, channels_last_ld=0):
+    """vol: [B, C, *vol] fp32 ; win: [nwin, C, *roi] (ld 0) or channels-last [nwin, *roi, ld] ; table: int32 [>=nwin, 4]
+    device tensor of (b, z0, y0, x0), b < 0 = unused slot."""
+    _need_gpu(vol, win, table)
+    assert vol.dtype == torch.float32 and vol.is_contiguous() and win.is_contiguous()
+    assert table.dtype == torch.int32 and table.is_contiguous() and table.shape[0] >= nwin
+    Cc = vol.shape[1]
+    VD, VH, VW = vol.shape[2:]
+    RD, RH, RW = win.shape[2:] if channels_last_ld == 0 else win.shape[1:4]
+    _ck(lib().msseg_sw_gather_batch(_p(vol), vol.stride(0), _p(win), channels_last_ld, dt(win), _p(table), nwin, Cc, VD, VH,
+                                    VW, RD, RH, RW, float(cval), _stream()), "sw_gather_batch")
+    return win
+
+
+def sw_blend_batch(win, imp, out, cnt, table, nwin, channels_last_ld=0):
+    """out: [B, C, *vol] fp32 ; cnt: [B, *vol] fp32 ; win as in sw_gather_batch (C = out.shape[1] channels used)."""
+    _need_gpu(win, imp, out, cnt, table)
+    assert out.is_contiguous() and cnt.is_contiguous() and win.is_contiguous() and imp.is_contiguous()
+    assert table.dtype == torch.int32 and table.is_contiguous() and table.shape[0] >= nwin
+    Cc = out.shape[1]
+    VD, VH, VW = out.shape[2:]
+    RD, RH, RW = imp.shape
+    _ck(lib().msseg_sw_blend_batch(_p(win), channels_last_ld, dt(win), _p(imp), _p(out), out.stride(0), _p(cnt),
+                                   cnt.stride(0), _p(table), nwin, Cc, VD, VH, VW, RD, RH, RW, _stream()), "sw_blend_batch")
 
 
 # --------------------------------------------------------------------------------------------

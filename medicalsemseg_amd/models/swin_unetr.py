@@ -265,13 +265,12 @@ class _DecoderFn(torch.autograd.Function):
         N, D, H, W, _ = x.shape
         logits_cl = torch.empty(N, D, H, W, LOGIT_LD, dtype=x.dtype, device=x.device)
         net._out_op.fwd(x, logits_cl[..., :net.out_channels])
-        logits = torch.empty(N, net.out_channels, D, H, W, dtype=torch.float32, device=x.device)
-        hip.to_channels_first(logits_cl[..., :net.out_channels], logits)
         if any(ctx.needs_input_grad):
             ctx.net, ctx.saved, ctx.last, ctx.nf, ctx.n_in = net, saved, x, nf, 3 + len(rest)
             ctx.feat_needs = [ctx.needs_input_grad[3 + i] for i in range(nf)]
         ctx.set_materialize_grads(False)
-        return logits
+        # [B, C, D, H, W] view of the channels-last logits rows (see models/unet.py): no NCDHW round trip to the loss
+        return logits_cl[..., :net.out_channels].permute(0, 4, 1, 2, 3)
 
     @staticmethod
     def backward(ctx, dlogits):
@@ -281,8 +280,11 @@ class _DecoderFn(torch.autograd.Function):
         E, Dd = net._enc_ops, net._dec_ops
         L = len(Dd)
         N, C, D, H, W = dlogits.shape
-        dl = torch.zeros(N, D, H, W, LOGIT_LD, dtype=net.compute_dtype, device=dlogits.device)
-        hip.to_channels_last(dlogits.contiguous(), dl[..., :C])
+        from ..losses import channels_last_grad
+        dl = channels_last_grad(dlogits, LOGIT_LD, net.compute_dtype)
+        if dl is None:
+            dl = torch.zeros(N, D, H, W, LOGIT_LD, dtype=net.compute_dtype, device=dlogits.device)
+            hip.to_channels_last(dlogits.contiguous(), dl[..., :C])
         g = net._out_op.bwd(ctx.last, dl, True, dy_channels=LOGIT_LD)
         dfeats = [None] * nf
         for k in range(0, L):

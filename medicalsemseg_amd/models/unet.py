@@ -134,6 +134,17 @@ class UNet(nn.Module):
         self._build_ops()  # parameters were replaced (.to / .cuda): re-bind the op objects
         return r
 
+    def infer_cl(self, x_cl):
+        """inference entry for callers that already hold channels-last windows in the compute dtype (sliding-window
+        inference): [N, D, H, W, Cin] -> logits [N, D, H, W, LOGIT_LD] (the first out_channels are valid); no autograd,
+        nothing retained, no layout conversion."""
+        if x_cl.dtype != self.compute_dtype or not x_cl.is_cuda or not x_cl.is_contiguous():
+            raise ValueError("infer_cl expects a contiguous channels-last GPU tensor in the compute dtype")
+        if any(int(d) % 16 for d in x_cl.shape[1:4]):
+            raise ValueError(f"UNet needs spatial dims divisible by 16, got {tuple(x_cl.shape[1:4])}")
+        with torch.no_grad():
+            return _forward_cl(self, x_cl, False)[0]
+
     def forward(self, x_in):
         vol = x_in[0] if isinstance(x_in, (tuple, list)) else x_in
         if not vol.is_cuda:
@@ -145,51 +156,69 @@ class UNet(nn.Module):
         return _UNetFn.apply(self, vol, *params)
 
 
+def _forward_cl(net: "UNet", x, keep: bool):
+    """x: channels-last [N, D, H, W, Cin] in the compute dtype -> (logits_cl [N, D, H, W, LOGIT_LD], saved, last, skips).
+    keep=False (inference): nothing is retained, every intermediate is released as soon as its consumer is issued."""
+    T = net.compute_dtype
+    N, D, H, W, _ = x.shape
+    dev = x.device
+    f = net.features
+    saved = {"enc": [], "dec": []}
+    # concat buffers [skip | up] for the 4 decoder levels (level i uses encoder output i)
+    cat = []
+    for i in range(4):
+        sh = (N, D >> i, H >> i, W >> i)
+        up_ch = f[i + 1] // 2 if i > 0 else f[1]
+        cat.append(torch.empty(sh + (f[i] + up_ch,), dtype=T, device=dev))
+    cur = x
+    skips = []
+    for lvl, (c0, c1) in enumerate(net._enc):
+        a0, s0 = c0.fwd(cur)
+        out = cat[lvl][..., :f[lvl]] if lvl < 4 else None
+        # the level's output goes into the decoder's concat buffer and, max-pooled by the same kernel, to the next level
+        pooled = torch.empty(N, D >> (lvl + 1), H >> (lvl + 1), W >> (lvl + 1), f[lvl], dtype=T, device=dev) if lvl < 4 else None
+        a1, s1 = c1.fwd(a0, out, pooled=pooled)
+        if keep:
+            saved["enc"].append((s0, s1))
+            skips.append(a1)
+        cur = pooled if lvl < 4 else a1
+        del a0, s0, s1
+    # decoder: levels 3..0
+    for j, (up, c0, c1) in enumerate(net._dec):
+        lvl = 3 - j
+        up_in = cur
+        up.fwd(up_in, cat[lvl][..., f[lvl]:])
+        a0, s0 = c0.fwd(cat[lvl])
+        a1, s1 = c1.fwd(a0)
+        if keep:
+            saved["dec"].append((up_in, s0, s1))
+        else:
+            cat[lvl] = None
+        cur = a1
+        del a0, s0, s1, up_in
+    logits_cl = torch.empty(N, D, H, W, LOGIT_LD, dtype=T, device=dev)
+    net._final.fwd(cur, logits_cl[..., :net.out_channels])
+    return logits_cl, saved, cur, skips
+
+
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net: UNet, vol, *params):
         T = net.compute_dtype
         N, Cin, D, H, W = vol.shape
         dev = vol.device
-        f = net.features
         need_grad = any(ctx.needs_input_grad)
         x = torch.empty(N, D, H, W, Cin, dtype=T, device=dev)
         hip.to_channels_last(vol.float() if vol.dtype not in (torch.float32, torch.bfloat16) else vol, x)
-        saved = {"enc": [], "dec": []}
-        # concat buffers [skip | up] for the 4 decoder levels (level i uses encoder output i)
-        cat = []
-        for i in range(4):
-            sh = (N, D >> i, H >> i, W >> i)
-            up_ch = f[i + 1] // 2 if i > 0 else f[1]
-            cat.append(torch.empty(sh + (f[i] + up_ch,), dtype=T, device=dev))
-        cur = x
-        skips = []
-        for lvl, (c0, c1) in enumerate(net._enc):
-            a0, s0 = c0.fwd(cur)
-            out = cat[lvl][..., :f[lvl]] if lvl < 4 else None
-            # the level's output goes into the decoder's concat buffer and, max-pooled by the same kernel, to the next level
-            pooled = torch.empty(N, D >> (lvl + 1), H >> (lvl + 1), W >> (lvl + 1), f[lvl], dtype=T, device=dev) if lvl < 4 else None
-            a1, s1 = c1.fwd(a0, out, pooled=pooled)
-            saved["enc"].append((s0, s1))
-            skips.append(a1)
-            cur = pooled if lvl < 4 else a1
-        # decoder: levels 3..0
-        for j, (up, c0, c1) in enumerate(net._dec):
-            lvl = 3 - j
-            up_in = cur
-            up.fwd(up_in, cat[lvl][..., f[lvl]:])
-            a0, s0 = c0.fwd(cat[lvl])
-            a1, s1 = c1.fwd(a0)
-            saved["dec"].append((up_in, s0, s1))
-            cur = a1
-        logits_cl = torch.empty(N, D, H, W, LOGIT_LD, dtype=T, device=dev)
-        net._final.fwd(cur, logits_cl[..., :net.out_channels])
-        logits = torch.empty(N, net.out_channels, D, H, W, dtype=torch.float32, device=dev)
-        hip.to_channels_first(logits_cl[..., :net.out_channels], logits)
+        logits_cl, saved, cur, skips = _forward_cl(net, x, need_grad)
         if need_grad:
             ctx.net, ctx.saved, ctx.last, ctx.skips = net, saved, cur, skips
         ctx.set_materialize_grads(False)
-        return logits
+        # The logits stay in their channels-last buffer (16-byte rows, compute dtype); what the caller gets is the
+        # [B, C, D, H, W] view of it, so the fp32 NCDHW round trip between the network and the loss never happens
+        # (losses.DiceCELoss reads / writes the channels-last buffers directly; any other consumer sees an ordinary
+        # strided tensor).
+        return logits_cl[..., :net.out_channels].permute(0, 4, 1, 2, 3)
 
     @staticmethod
     def backward(ctx, dlogits):
@@ -201,8 +230,11 @@ class _UNetFn(torch.autograd.Function):
         f = net.features
         N, C, D, H, W = dlogits.shape
         dev = dlogits.device
-        dl = torch.zeros(N, D, H, W, LOGIT_LD, dtype=T, device=dev)
-        hip.to_channels_last(dlogits.contiguous(), dl[..., :C])
+        from ..losses import channels_last_grad
+        dl = channels_last_grad(dlogits, LOGIT_LD, T)   # the loss wrote [N, D, H, W, LOGIT_LD] rows (zero padded) itself
+        if dl is None:
+            dl = torch.zeros(N, D, H, W, LOGIT_LD, dtype=T, device=dev)
+            hip.to_channels_last(dlogits.contiguous(), dl[..., :C])
         layers.WGRAD_SIDE.begin(dev)
         try:
             return _UNetFn._backward_body(ctx, net, saved, dl, f, n_in)

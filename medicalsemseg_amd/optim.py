@@ -114,9 +114,41 @@ class FlatAdamW(torch.optim.Optimizer):
         return {"flat": True, "step": self._step, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
+    def _load_torch_adamw(self, sd):
+        """state dict written by torch.optim.AdamW over the same param groups (the reference's checkpoints,
+        /root/reference/utils/misc.py:268-283): per-parameter exp_avg / exp_avg_sq go to their slices of the flat
+        moments, in param-group order (timm add_weight_decay: [no_decay, decay], as `add_weight_decay` here)."""
+        groups = sd["param_groups"]
+        if [len(g["params"]) for g in groups] != [len(g["params"]) for g in self.param_groups]:
+            raise ValueError("optimizer state does not match the parameter groups of this model")
+        ids = [i for g in groups for i in g["params"]]
+        steps = set()
+        off = 0
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        for (p, _), i in zip(self._views, ids):
+            k = p.numel()
+            st = sd["state"].get(i)
+            if st is not None:
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != parameter {tuple(p.shape)}")
+                self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            off += k
+        if len(steps) > 1:
+            raise ValueError("parameters with different step counts cannot share the fused optimiser step")
+        return steps.pop() if steps else 0, groups
+
     def load_state_dict(self, sd):
         if not sd.get("flat"):
-            raise ValueError("not a FlatAdamW state dict")
+            if "state" not in sd or "param_groups" not in sd:
+                raise ValueError("neither a FlatAdamW nor a torch.optim.AdamW state dict")
+            self._step, groups = self._load_torch_adamw(sd)
+            self._hyper[1:2].fill_(float(self._step))
+            for g, s_ in zip(self.param_groups, groups):
+                g.update({k: v for k, v in s_.items() if k in ("lr", "betas", "eps", "weight_decay", "initial_lr")})
+            layers.bump_weights_epoch()
+            return
         self._step = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])

@@ -182,14 +182,17 @@ def load_model(cfg, model_without_ddp, optimizer=None, loss_scaler=None, schedul
         return
     if str(cfg.resume).startswith("http"):
         raise RuntimeError("remote checkpoints are not supported (no network)")
-    ck = torch.load(cfg.resume, map_location="cpu", weights_only=True)
+    # weights-only load; the reference stores `cfg` as an argparse.Namespace (/root/reference/utils/misc.py:268-283),
+    # an inert container that is allow-listed instead of unpickling arbitrary globals
+    import argparse
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        ck = torch.load(cfg.resume, map_location="cpu", weights_only=True)
     model_without_ddp.load_state_dict(ck["model"])
     print(f"Resume checkpoint {cfg.resume}")
     if optimizer is not None and "optimizer" in ck and "epoch" in ck and not getattr(cfg, "eval", False):
-        try:
-            optimizer.load_state_dict(ck["optimizer"])
-        except Exception as e:  # optimiser layout differs (e.g. checkpoint written by torch AdamW)
-            print(f"optimizer state not restored: {e}")
+        # FlatAdamW takes its own layout or a torch.optim.AdamW state dict (converted in param-group order); anything
+        # else fails loudly rather than silently restarting the moments mid-schedule
+        optimizer.load_state_dict(ck["optimizer"])
         cfg.start_epoch = ck["epoch"] + 1
         if loss_scaler is not None and ck.get("scaler") is not None:
             loss_scaler.load_state_dict(ck["scaler"])
