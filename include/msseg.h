@@ -125,6 +125,22 @@ int msseg_conv3d_k1_head_dgrad_inbwd(const void* dy, long long lddy, const float
                                      const float* fwd_stats, const float* gamma, const float* beta, float slope, float eps,
                                      float* red, float* dgamma, float* dbeta, int accumulate, void* scratch,
                                      size_t scratch_bytes, int dtype, msseg_stream_t stream);
+/* The head reading the RAW conv output `x` of the last conv + InstanceNorm + LeakyReLU unit (N samples of S voxels):
+ * y = conv1x1(T(lrelu(IN(x) * gamma + beta))) with the normalisation applied in registers -- the unit's activation is
+ * never written.  stats: [N][Cin][2] (sum, sum of squares) of x.  Replaces InstanceNorm3d + LeakyReLU + final Conv3d(k=1)
+ * of MONAI BasicUNet (TwoConv tail + final_conv). */
+int msseg_conv3d_k1_head_norm_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
+                                  float slope, float eps, const float* w, const float* bias, void* y, long long ldy, int N,
+                                  long long S, int Cin, int Cout, int dtype, msseg_stream_t stream);
+/* msseg_conv3d_k1_head_dgrad_inbwd plus the head's weight gradient dw[Cout][C] (+)= sum_v dy[v][k] * a[v][c] with the
+ * activation a recomputed from yraw (as the fused forward does): one streaming pass for da, the InstanceNorm-backward sums
+ * and dw. */
+int msseg_conv3d_k1_head_bwd_fused(const void* dy, long long lddy, const float* w, void* da, long long ldda, int N,
+                                   long long S, int C, int Cout, const void* yraw, long long ldyraw, const float* fwd_stats,
+                                   const float* gamma, const float* beta, float slope, float eps, float* red, float* dgamma,
+                                   float* dbeta, int accumulate, float* dw, int dw_accumulate, void* scratch,
+                                   size_t scratch_bytes, int dtype, msseg_stream_t stream);
+
 /* Conv3d with few input channels (Cin*k^3 <= 128), kernel k, stride s, pad p, gathered im2col-style:
  * the 1->C stem convs and PatchEmbed3D.proj (models/blocks/patch_embeddings.py:109). */
 int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,

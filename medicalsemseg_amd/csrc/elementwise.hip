@@ -717,9 +717,39 @@ struct HeadBwdParams {
     long long S; int C, Cout; float eps, slope;
     int groups, rows_par; long long rows_per_block;
     float* ws;
+    int want_dw;                         // also accumulate dW[k][c] = sum_v dy[v][k] * a[v][c], a = T(lrelu(IN(x))) recomputed
 };
 
-template <typename T>
+// second step of the head backward: rows ws[(n * nblk + b)][C][nper] (nper = 2, or 6 with the weight gradient) ->
+// red[n][c][0..1], dbeta / dgamma (+)= sum_n, dW[k][c] (+)= sum_{n, b} -- one block, fixed order (bit-reproducible)
+struct HeadFinArgs {
+    const float* ws; int N, nblk, C, nper, Cout; float* red; float* dbeta; float* dgamma; float* dw; int acc_norm, acc_dw;
+};
+__global__ __launch_bounds__(256) void head_finalize_kernel(const HeadFinArgs a) {
+    const int L = a.C * a.nper;
+    for (int o = threadIdx.x; o < L; o += 256) {
+        const int c = o / a.nper, k = o % a.nper;
+        float tot = 0.f;
+        for (int n = 0; n < a.N; ++n) {
+            const float* src = a.ws + (long long)n * a.nblk * L + o;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int b = 0;
+            for (; b + 3 < a.nblk; b += 4) {
+                s0 += src[(long long)b * L]; s1 += src[(long long)(b + 1) * L];
+                s2 += src[(long long)(b + 2) * L]; s3 += src[(long long)(b + 3) * L];
+            }
+            for (; b < a.nblk; ++b) s0 += src[(long long)b * L];
+            const float t = (s0 + s1) + (s2 + s3);
+            if (k < 2) a.red[((long long)n * a.C + c) * 2 + k] = t;
+            tot += t;
+        }
+        if (k == 0) { if (a.dbeta) a.dbeta[c] = a.acc_norm ? a.dbeta[c] + tot : tot; }
+        else if (k == 1) { if (a.dgamma) a.dgamma[c] = a.acc_norm ? a.dgamma[c] + tot : tot; }
+        else if (k - 2 < a.Cout && a.dw) a.dw[(k - 2) * a.C + c] = a.acc_dw ? a.dw[(k - 2) * a.C + c] + tot : tot;
+    }
+}
+
+template <typename T, bool DW>
 __global__ __launch_bounds__(RED_THREADS) void head_dgrad_inbwd_kernel(const HeadBwdParams p) {
     constexpr int WD = DT<T>::EPC;
     __shared__ float red[RED_THREADS * 2 * WD];
@@ -735,6 +765,7 @@ __global__ __launch_bounds__(RED_THREADS) void head_dgrad_inbwd_kernel(const Hea
         const int gg = gbase + g;
         const bool act = gg * WD < p.C;
         float mean[WD], rstd[WD], sc[WD], sh[WD], a0[WD], a1[WD], wv[4][WD];
+        float gw[DW ? 4 : 1][WD];
 #pragma unroll
         for (int e = 0; e < WD; ++e) {
             const int c = act ? gg * WD + e : 0;
@@ -744,6 +775,8 @@ __global__ __launch_bounds__(RED_THREADS) void head_dgrad_inbwd_kernel(const Hea
             a0[e] = a1[e] = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) wv[k][e] = k < p.Cout ? (float)(T)p.w[k * p.C + c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < (DW ? 4 : 1); ++k) gw[k][e] = 0.f;
         }
         if (act && rl < p.rows_par) {
 #pragma unroll 4
@@ -762,30 +795,42 @@ __global__ __launch_bounds__(RED_THREADS) void head_dgrad_inbwd_kernel(const Hea
                     const float dz = z > 0.f ? da : da * p.slope;
                     a0[e] += dz;
                     a1[e] += dz * ((xc.v[e] - mean[e]) * rstd[e]);
+                    if constexpr (DW) {
+                        const float av = (float)(T)(z > 0.f ? z : z * p.slope);   // the activation as the forward stored it
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) gw[k][e] += dc.v[k] * av;
+                    }
                 }
                 o.store(dan + r * p.ldda + gg * WD);
             }
         }
-        __syncthreads();
+        constexpr int NPER = DW ? 6 : 2;
+        float* wsb = p.ws + ((long long)n * gridDim.x + blockIdx.x) * p.C * NPER;
 #pragma unroll
-        for (int e = 0; e < WD; ++e) {
-            red[(threadIdx.x * WD + e) * 2 + 0] = a0[e];
-            red[(threadIdx.x * WD + e) * 2 + 1] = a1[e];
-        }
-        __syncthreads();
-        block_rows_reduce<WD>(red, p.groups, p.rows_par, g, rl, act);
-        if (act && rl == 0) {
-            const int kmax = p.rows_par < RED_STAGE2 ? p.rows_par : RED_STAGE2;
+        for (int round = 0; round < NPER / 2; ++round) {   // the two-value block reduction, once per value pair
+            __syncthreads();
 #pragma unroll
             for (int e = 0; e < WD; ++e) {
-                float a = 0.f, b = 0.f;
-                for (int k = 0; k < kmax; ++k) {
-                    a += red[((k * p.groups + g) * WD + e) * 2 + 0];
-                    b += red[((k * p.groups + g) * WD + e) * 2 + 1];
+                float v0, v1;
+                if (round == 0) { v0 = a0[e]; v1 = a1[e]; }
+                else { v0 = gw[DW ? 2 * round - 2 : 0][e]; v1 = gw[DW ? 2 * round - 1 : 0][e]; }
+                red[(threadIdx.x * WD + e) * 2 + 0] = v0;
+                red[(threadIdx.x * WD + e) * 2 + 1] = v1;
+            }
+            __syncthreads();
+            block_rows_reduce<WD>(red, p.groups, p.rows_par, g, rl, act);
+            if (act && rl == 0) {
+                const int kmax = p.rows_par < RED_STAGE2 ? p.rows_par : RED_STAGE2;
+#pragma unroll
+                for (int e = 0; e < WD; ++e) {
+                    float a = 0.f, b = 0.f;
+                    for (int k = 0; k < kmax; ++k) {
+                        a += red[((k * p.groups + g) * WD + e) * 2 + 0];
+                        b += red[((k * p.groups + g) * WD + e) * 2 + 1];
+                    }
+                    wsb[(gg * WD + e) * NPER + 2 * round + 0] = a;
+                    wsb[(gg * WD + e) * NPER + 2 * round + 1] = b;
                 }
-                float* wsb = p.ws + ((long long)n * gridDim.x + blockIdx.x) * p.C * 2;
-                wsb[(gg * WD + e) * 2 + 0] = a;
-                wsb[(gg * WD + e) * 2 + 1] = b;
             }
         }
     }
@@ -1053,6 +1098,54 @@ __global__ __launch_bounds__(256) void conv1x1_head_kernel(const T* __restrict__
     }
 }
 
+// The same head reading the RAW conv output of the last conv+norm unit: a = T(lrelu(IN(x))) is formed in registers, so
+// the normalised activation of that unit is never written (the backward recomputes it as well, head_dgrad_inbwd_kernel).
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void conv1x1_head_norm_kernel(const T* __restrict__ x, long long ldx,
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float slope, float eps, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, T* __restrict__ y,
+                                                                long long ldy, long long S, int Cin) {
+    constexpr int WD = DT<T>::EPC;
+    __shared__ float wS[COUT * 64];
+    __shared__ float scS[64], shS[64];
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < COUT * Cin; i += 256) wS[i] = (float)(T)w[i];
+    for (int c = threadIdx.x; c < Cin; c += 256) {
+        float mean, rstd;
+        mean_rstd(stats, n, Cin, c, S, eps, mean, rstd);
+        const float sc = rstd * (gamma ? gamma[c] : 1.f);
+        scS[c] = sc;
+        shS[c] = (beta ? beta[c] : 0.f) - mean * sc;
+    }
+    __syncthreads();
+    float b[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) b[c] = bias ? bias[c] : 0.f;
+    const T* xn = x + (long long)n * S * ldx;
+    T* yn = y + (long long)n * S * ldy;
+    for (long long v = blockIdx.x * 256LL + threadIdx.x; v < S; v += (long long)gridDim.x * 256) {
+        float acc[COUT];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = b[c];
+        const T* xr = xn + v * ldx;
+        for (int k0 = 0; k0 < Cin; k0 += WD) {
+            Chunk<T> xc; xc.load(xr + k0);
+#pragma unroll
+            for (int e = 0; e < WD; ++e) {
+                const float z = xc.v[e] * scS[k0 + e] + shS[k0 + e];
+                const float a = (float)(T)(z > 0.f ? z : z * slope);
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) acc[c] += a * wS[c * Cin + k0 + e];
+            }
+        }
+        T* yr = yn + v * ldy;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) DT<T>::st(yr + c, acc[c]);
+    }
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, const uint8_t* __restrict__ decay, long long n, float lr, float b1,
                              float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* gscale,
@@ -1232,11 +1325,11 @@ int msseg_conv3d_k1_head_fwd(const void* x, long long ldx, const float* w, const
     return MSSEG_OK;
 }
 
-int msseg_conv3d_k1_head_dgrad_inbwd(const void* dy, long long lddy, const float* w, void* da, long long ldda, int N,
-                                     long long S, int C, int Cout, const void* yraw, long long ldyraw,
-                                     const float* fwd_stats, const float* gamma, const float* beta, float slope, float eps,
-                                     float* red, float* dgamma, float* dbeta, int accumulate, void* scratch,
-                                     size_t scratch_bytes, int dtype, msseg_stream_t stream) {
+static int head_bwd_impl(const void* dy, long long lddy, const float* w, void* da, long long ldda, int N, long long S,
+                         int C, int Cout, const void* yraw, long long ldyraw, const float* fwd_stats, const float* gamma,
+                         const float* beta, float slope, float eps, float* red, float* dgamma, float* dbeta, int accumulate,
+                         float* dw, int dw_accumulate, void* scratch, size_t scratch_bytes, int dtype,
+                         msseg_stream_t stream) {
     if (!dy || !w || !da || !yraw || !fwd_stats || !red || N < 1 || S < 1)
         MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_dgrad_inbwd: bad args");
     if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_dgrad_inbwd: bad dtype");
@@ -1246,20 +1339,69 @@ int msseg_conv3d_k1_head_dgrad_inbwd(const void* dy, long long lddy, const float
         (lddy % epc) || ((uintptr_t)dy & 15))
         MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_dgrad_inbwd: needs <= 4 classes in 16-byte aligned gradient rows and "
                                  "16-byte channel chunks (C=%d, Cout=%d, lddy=%lld)", C, Cout, lddy);
-    HeadBwdParams p{dy, lddy, w, yraw, ldyraw, fwd_stats, gamma, beta, da, ldda, S, C, Cout, eps, slope, 0, 0, 0, nullptr};
+    HeadBwdParams p{dy, lddy, w, yraw, ldyraw, fwd_stats, gamma, beta, da, ldda, S, C, Cout, eps, slope, 0, 0, 0, nullptr, 0};
     p.ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+    p.want_dw = dw != nullptr;
+    const int nper = dw ? 6 : 2;
     const RowMap m = row_map(C, epc, RED_THREADS);
     p.groups = m.groups; p.rows_par = m.rows_par;
-    long long blocks = reduce_blocks(S, m.rows_par, N, C, 2);
+    long long blocks = reduce_blocks(S, m.rows_par, N, C, nper);
     p.rows_per_block = ceil_div_ll(S, blocks);
     blocks = ceil_div_ll(S, p.rows_per_block);
     dim3 grid((unsigned)blocks, N);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(head_dgrad_inbwd_kernel<float>, grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p),
-               hipLaunchKernelGGL(head_dgrad_inbwd_kernel<bf16_t>, grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p));
+    if (dw) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_inbwd_kernel<float, true>), grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p),
+                   hipLaunchKernelGGL((head_dgrad_inbwd_kernel<bf16_t, true>), grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((head_dgrad_inbwd_kernel<float, false>), grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p),
+                   hipLaunchKernelGGL((head_dgrad_inbwd_kernel<bf16_t, false>), grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p));
+    }
     MSSEG_CHECK_LAUNCH("conv3d_k1_head_dgrad_inbwd");
-    FinalizeArgs a{p.ws, N, (int)blocks, C, 2, 2, red, dbeta, dgamma, accumulate};
-    hipLaunchKernelGGL(channels_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
-    MSSEG_CHECK_LAUNCH("channels_finalize");
+    HeadFinArgs a{p.ws, N, (int)blocks, C, nper, Cout, red, dbeta, dgamma, dw, accumulate, dw_accumulate};
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    MSSEG_CHECK_LAUNCH("head_finalize");
+    return MSSEG_OK;
+}
+
+int msseg_conv3d_k1_head_dgrad_inbwd(const void* dy, long long lddy, const float* w, void* da, long long ldda, int N,
+                                     long long S, int C, int Cout, const void* yraw, long long ldyraw,
+                                     const float* fwd_stats, const float* gamma, const float* beta, float slope, float eps,
+                                     float* red, float* dgamma, float* dbeta, int accumulate, void* scratch,
+                                     size_t scratch_bytes, int dtype, msseg_stream_t stream) {
+    return head_bwd_impl(dy, lddy, w, da, ldda, N, S, C, Cout, yraw, ldyraw, fwd_stats, gamma, beta, slope, eps, red, dgamma,
+                         dbeta, accumulate, nullptr, 0, scratch, scratch_bytes, dtype, stream);
+}
+
+int msseg_conv3d_k1_head_bwd_fused(const void* dy, long long lddy, const float* w, void* da, long long ldda, int N,
+                                   long long S, int C, int Cout, const void* yraw, long long ldyraw, const float* fwd_stats,
+                                   const float* gamma, const float* beta, float slope, float eps, float* red, float* dgamma,
+                                   float* dbeta, int accumulate, float* dw, int dw_accumulate, void* scratch,
+                                   size_t scratch_bytes, int dtype, msseg_stream_t stream) {
+    if (!dw) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_bwd_fused: dw is required");
+    return head_bwd_impl(dy, lddy, w, da, ldda, N, S, C, Cout, yraw, ldyraw, fwd_stats, gamma, beta, slope, eps, red, dgamma,
+                         dbeta, accumulate, dw, dw_accumulate, scratch, scratch_bytes, dtype, stream);
+}
+
+int msseg_conv3d_k1_head_norm_fwd(const void* x, long long ldx, const float* stats, const float* gamma, const float* beta,
+                                  float slope, float eps, const float* w, const float* bias, void* y, long long ldy, int N,
+                                  long long S, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+    if (!x || !stats || !w || !y || N < 1 || S < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_norm: bad args");
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_norm: bad dtype");
+    if ((gamma == nullptr) != (beta == nullptr)) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_norm: gamma/beta go together");
+    if (Cout < 1 || Cout > 4 || Cin < 1 || Cin > 64 || !vec_ok(x, ldx, Cin, esz) || ldy < Cout)
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_norm: needs 1 <= Cout <= 4, Cin <= 64 in 16-byte chunks (got %d -> %d)", Cin, Cout);
+    long long gx = ceil_div_ll(S, 256);
+    const long long cap = (long long)msseg_num_cus() * 16 / N + 1;
+    if (gx > cap) gx = cap;
+    dim3 grid((unsigned)gx, N);
+#define HEADN(T_, C_) hipLaunchKernelGGL((conv1x1_head_norm_kernel<T_, C_>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                         (const T_*)x, ldx, stats, gamma, beta, slope, eps, w, bias, (T_*)y, ldy, S, Cin)
+#define HEADN_C(T_) do { if (Cout == 1) HEADN(T_, 1); else if (Cout == 2) HEADN(T_, 2); else if (Cout == 3) HEADN(T_, 3); else HEADN(T_, 4); } while (0)
+    DISPATCH_T(dtype, HEADN_C(float), HEADN_C(bf16_t));
+#undef HEADN_C
+#undef HEADN
+    MSSEG_CHECK_LAUNCH("conv3d_k1_head_norm");
     return MSSEG_OK;
 }
 

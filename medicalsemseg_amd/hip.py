@@ -57,6 +57,9 @@ SIGNATURES = {
     "msseg_conv3d_stem_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_k1_head_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _ll, _i, _i, _vp, _ll, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                           _vp, _i, _vp, _sz, _i, _vp], _i),
+    "msseg_conv3d_k1_head_norm_fwd": ([_vp, _ll, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _ll, _i, _ll, _i, _i, _i, _vp], _i),
+    "msseg_conv3d_k1_head_bwd_fused": ([_vp, _ll, _vp, _vp, _ll, _i, _ll, _i, _i, _vp, _ll, _vp, _vp, _vp, _f, _f, _vp, _vp,
+                                        _vp, _i, _vp, _i, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_k1_head_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_k1_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_gather_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -370,6 +373,31 @@ def conv3d_k1_head_dgrad_inbwd(dy, w, da, cin, cout, yraw, fwd_stats, gamma, bet
                                                _p(fwd_stats), _p(gamma), _p(beta), slope, eps, _p(red), _p(dgamma),
                                                _p(dbeta), int(accumulate), _p(sc), sc.numel(), dt(dy), _stream()),
         "conv3d_k1_head_dgrad_inbwd")
+    return red
+
+
+def conv3d_k1_head_norm(yraw, stats, gamma, beta, slope, eps, w, bias, y, cin, cout):
+    """y = conv1x1(lrelu(instance_norm(yraw))) for a head with <= 4 classes, normalisation applied on load"""
+    _need_gpu(yraw, stats, w, y)
+    N = yraw.shape[0]
+    S = yraw.numel() // yraw.shape[-1] // N
+    _ck(lib().msseg_conv3d_k1_head_norm_fwd(_p(yraw), ld(yraw), _p(stats), _p(gamma), _p(beta), slope, eps, _p(w), _p(bias),
+                                            _p(y), ld(y), N, S, cin, cout, dt(yraw), _stream()), "conv3d_k1_head_norm_fwd")
+    return y
+
+
+def conv3d_k1_head_bwd_fused(dy, w, da, cin, cout, yraw, fwd_stats, gamma, beta, slope, eps, dw, dw_accumulate,
+                             dgamma=None, dbeta=None, accumulate=False):
+    """conv3d_k1_head_dgrad_inbwd + the head's weight gradient dw[cout][cin] from the recomputed activation"""
+    _need_gpu(dy, w, da, yraw, fwd_stats, dw)
+    N = dy.shape[0]
+    S = dy.numel() // dy.shape[-1] // N
+    red = torch.empty(N, cin, 2, dtype=torch.float32, device=dy.device)
+    sc = scratch(dy.device)
+    _ck(lib().msseg_conv3d_k1_head_bwd_fused(_p(dy), ld(dy), _p(w), _p(da), ld(da), N, S, cin, cout, _p(yraw), ld(yraw),
+                                             _p(fwd_stats), _p(gamma), _p(beta), slope, eps, _p(red), _p(dgamma),
+                                             _p(dbeta), int(accumulate), _p(dw), int(dw_accumulate), _p(sc), sc.numel(),
+                                             dt(dy), _stream()), "conv3d_k1_head_bwd_fused")
     return red
 
 

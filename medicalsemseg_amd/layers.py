@@ -312,6 +312,36 @@ class Conv1:
             return y, hip.channel_stats(y)
         return y
 
+    # ---- segmentation head fused with the InstanceNorm + LeakyReLU of the unit in front of it ----
+    def head_norm_ok(self, yraw) -> bool:
+        """the head can read the RAW conv output of the last conv+norm unit and normalise on load (forward) / recompute the
+        activation (backward): the unit's activation tensor is then never written or read"""
+        epc = 16 // yraw.element_size()
+        return (self.cout <= 4 and self.cin <= 64 and self.cin % epc == 0 and yraw.shape[-1] == self.cin
+                and hip.ld(yraw) % epc == 0 and yraw.data_ptr() % 16 == 0 and self.w.is_contiguous()
+                and not os.environ.get("MSSEG_NO_HEAD_KERNEL") and not os.environ.get("MSSEG_NO_HEAD_FUSE"))
+
+    def fwd_norm(self, yraw, stats, nrm, out):
+        return hip.conv3d_k1_head_norm(yraw, stats, nrm.gamma, nrm.beta, nrm.slope, nrm.eps, self.w.detach(), self.b, out,
+                                       self.cin, self.cout)
+
+    def bwd_norm(self, dy, dy_channels, nrm, yraw, stats):
+        """backward of fwd_norm: returns (da, red) for the unit's `bwd(..., red=red)`; weight / bias gradients land in .grad"""
+        dyk = dy[..., :dy_channels]
+        dx = torch.empty(yraw.shape, dtype=yraw.dtype, device=yraw.device)
+        dg, db, acc = _norm_grad_bufs(nrm)
+        if self.b is not None and self.b.requires_grad:
+            g, bacc = _grad_buf(self.b)
+            hip.channel_sum(dy[..., :self.cout], g, bacc)
+        if self.w.requires_grad:
+            gw, wacc = _grad_buf(self.w)
+            red = hip.conv3d_k1_head_bwd_fused(dyk, self.w.detach(), dx, self.cin, self.cout, yraw, stats, nrm.gamma, nrm.beta,
+                                               nrm.slope, nrm.eps, gw, wacc, dg, db, acc)
+        else:
+            red = hip.conv3d_k1_head_dgrad_inbwd(dyk, self.w.detach(), dx, self.cin, self.cout, yraw, stats, nrm.gamma,
+                                                 nrm.beta, nrm.slope, nrm.eps, dg, db, acc)
+        return dx, red
+
     def bwd(self, x, dy, need_dx=True, dy_channels=None, next_norm=None):
         """dy may carry zero-padded channels (dy_channels = padded count, multiple of 8).
         next_norm = (InstNormAct, yraw, stats, act) of the layer whose activation is this conv's input: its

@@ -189,15 +189,28 @@ def _forward_cl(net: "UNet", x, keep: bool):
         up_in = cur
         up.fwd(up_in, cat[lvl][..., f[lvl]:])
         a0, s0 = c0.fwd(cat[lvl])
-        a1, s1 = c1.fwd(a0)
+        if lvl == 0:
+            # last unit: only its raw conv output + statistics; the head normalises on load (no activation tensor)
+            y1, st1 = c1.conv.fwd(a0, want_stats=True)
+            if net._final.head_norm_ok(y1):
+                a1, s1 = None, (a0, y1, st1, None)
+            else:
+                a1, st1 = c1.norm.fwd(y1, stats=st1)
+                s1 = (a0, y1, st1, a1)
+        else:
+            a1, s1 = c1.fwd(a0)
         if keep:
             saved["dec"].append((up_in, s0, s1))
         else:
             cat[lvl] = None
         cur = a1
+        last_unit = s1
         del a0, s0, s1, up_in
     logits_cl = torch.empty(N, D, H, W, LOGIT_LD, dtype=T, device=dev)
-    net._final.fwd(cur, logits_cl[..., :net.out_channels])
+    if cur is None:
+        net._final.fwd_norm(last_unit[1], last_unit[2], net._dec[3][2].norm, logits_cl[..., :net.out_channels])
+    else:
+        net._final.fwd(cur, logits_cl[..., :net.out_channels])
     return logits_cl, saved, cur, skips
 
 
@@ -256,8 +269,12 @@ class _UNetFn(torch.autograd.Function):
         def pair(r):                                     # (dx, red) with or without the fused sums
             return r if isinstance(r, tuple) else (r, None)
 
-        g, red_c1 = pair(net._final.bwd(ctx.last, dl, True, dy_channels=LOGIT_LD,
-                                        next_norm=unit_norm(net._dec[3][2], saved["dec"][3][2])))
+        if ctx.last is None:   # head fused with the last unit's InstanceNorm + LeakyReLU (forward never wrote its activation)
+            lu = saved["dec"][3][2]
+            g, red_c1 = net._final.bwd_norm(dl, LOGIT_LD, net._dec[3][2].norm, lu[1], lu[2])
+        else:
+            g, red_c1 = pair(net._final.bwd(ctx.last, dl, True, dy_channels=LOGIT_LD,
+                                            next_norm=unit_norm(net._dec[3][2], saved["dec"][3][2])))
         skip_grads = [None] * 4
         for j in range(3, -1, -1):  # decoder levels 0..3 in reverse order of execution
             up, c0, c1 = net._dec[j]

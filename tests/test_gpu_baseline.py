@@ -99,7 +99,7 @@ def test_unet_base_48_vs_oracle(dtype):
     o = out.detach().float().cpu()
     if dtype == torch.float32:
         np.testing.assert_allclose(o.numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=1e-4)
-        assert abs(float(loss) - float(loss_ref)) < 1e-4
+        assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4
         tot, worst = _grad_rel_l2(net, ref)
         print(f"[fp32] UNet base 48^3 whole-net grad rel-L2 {tot:.3e}, worst {worst}")
         assert tot < 1e-3
@@ -188,21 +188,23 @@ def test_unet_base_96_full_size_step_properties():
     lg, pg = run(True)
     print("eager losses", le, "graph losses", lg)
     assert all(np.isfinite(le)) and le[-1] < le[0]
-    # not bit-identical: the DiceCE partial sums use float atomics (order varies run to run)
-    assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-3
-    assert float((pe - pg).norm() / pe.norm()) < 1e-3
+    # not bit-identical: the DiceCE partial sums use float atomics (order varies run to run), and AdamW's first steps
+    # turn a last-bit difference of a near-zero gradient into a +-lr difference of that parameter
+    assert max(abs(a - b) for a, b in zip(le, lg)) < 1e-4
+    assert float((pe - pg).norm() / pe.norm()) < 1e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_swin_unetr_48_config_vs_oracle(dtype):
-    """BASELINE configs[3]'s shape (hidden 48, depths 2-2-2-2, heads 3-6-12-24, windows 6-6-6-3, patch 2) at 48^3"""
+    """BASELINE configs[3] itself: hidden 48, depths 2-2-2-2, heads 3-6-12-24, windows 6-6-6-3, patch 2 at 96^3 (the
+    5-level pyramid 48-24-12-6-3 needs the full patch size; one sample)"""
     from medicalsemseg_amd.losses import DiceCELoss
     from medicalsemseg_amd.models import swin_unetr as P
     from oracle import swin as O
     from oracle.losses import dice_ce_loss
     from tests.golden_util import det_tensor
     torch.manual_seed(0)
-    vol, hs = (48, 48, 48), 48
+    vol, hs = (96, 96, 96), 48
     kw = dict(patch_size=(2, 2, 2), in_chans=1, embed_dim=hs, depths=(2, 2, 2, 2), num_heads=(3, 6, 12, 24),
               window_size=(6, 6, 6, 3))
     ref = O.SwinUNETRCustom(O.SwinTransformerNNFormer(vol, **kw), 1, 3, hs, 2)
@@ -211,7 +213,7 @@ def test_swin_unetr_48_config_vs_oracle(dtype):
     net.load_state_dict(dict(ref.state_dict()), strict=True)
     net = net.to(DEV)
     x = det_tensor("su48_x", (1, 1) + vol)
-    y = _blobs(1, 48, 3, 3)
+    y = _blobs(1, 96, 3, 3)
     out_ref = ref((x, None, None))
     loss_ref = dice_ce_loss(out_ref, y)
     loss_ref.backward()
@@ -222,7 +224,7 @@ def test_swin_unetr_48_config_vs_oracle(dtype):
     tot, worst = _grad_rel_l2(net, ref, skip_bias_before_norm=False)
     scale = float(out_ref.abs().max())
     err = float((o - out_ref.detach()).abs().max()) / scale
-    print(f"[{dtype}] Swin-UNETR-48 48^3: logits err/scale {err:.3e}, loss {float(loss):.5f} vs {float(loss_ref):.5f}, "
+    print(f"[{dtype}] Swin-UNETR-48 96^3: logits err/scale {err:.3e}, loss {float(loss):.5f} vs {float(loss_ref):.5f}, "
           f"grad rel-L2 {tot:.3e}, worst {worst}")
     if dtype == torch.float32:
         np.testing.assert_allclose(o.numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=2e-4 * max(scale, 1.0))

@@ -664,3 +664,45 @@ def test_conv3d_k1_head_dgrad_inbwd(dtype, cin, cout):
     assert float((red.cpu() - red_ref).abs().max()) / sc < tol
     assert float((db.cpu() - red_ref[..., 0].sum(0)).abs().max()) / sc < tol
     assert float((dg.cpu() - red_ref[..., 1].sum(0)).abs().max()) / sc < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,affine", [(32, 3, True), (48, 2, False), (64, 4, True)])
+def test_conv3d_k1_head_norm_fused_fwd_bwd(dtype, cin, cout, affine):
+    """head fused with the InstanceNorm + LeakyReLU in front of it (normalise on load; backward recomputes the activation
+    and also produces the head's weight gradient) == the unfused kernels on the same operands"""
+    from medicalsemseg_amd import hip
+    DEV = _dev()
+    N, sp = 2, (6, 10, 12)
+    yraw = gen(N, cin, *sp, seed=51)
+    dl = gen(N, cout, *sp, seed=52)
+    w = gen(cout, cin, seed=53, scale=0.2).to(DEV)
+    b = gen(cout, seed=56).to(DEV)
+    gamma = (gen(cin, seed=54) * 0.3 + 1.0).to(DEV) if affine else None
+    beta = (gen(cin, seed=55) * 0.3).to(DEV) if affine else None
+    yc = cl(yraw, dtype, DEV)
+    stats = hip.channel_stats(yc)
+    # unfused: normalise (stores the activation), head on the activation
+    act = torch.empty_like(yc)
+    hip.instnorm_act_fwd(yc, stats, gamma, beta, act, 0.1, 1e-5)
+    ref = torch.zeros(N, *sp, 8, device=DEV, dtype=dtype)
+    hip.conv3d_k1_head(act, w, b, ref[..., :cout], cin, cout)
+    got = torch.zeros(N, *sp, 8, device=DEV, dtype=dtype)
+    hip.conv3d_k1_head_norm(yc, stats, gamma, beta, 0.1, 1e-5, w, b, got[..., :cout], cin, cout)
+    check(got[..., :cout], ref[..., :cout], dtype, "fused head forward", scale=float(ref.float().abs().max()))
+    # backward: da / sums as the unfused kernel, dw against einsum on the stored activation
+    dlc = torch.zeros(N, *sp, 8, device=DEV, dtype=dtype)
+    dlc[..., :cout] = cl(dl, dtype, DEV)
+    dx0, dx1 = torch.empty_like(yc), torch.empty_like(yc)
+    dg0, db0 = (torch.zeros(cin, device=DEV), torch.zeros(cin, device=DEV)) if affine else (None, None)
+    dg1, db1 = (torch.zeros(cin, device=DEV), torch.zeros(cin, device=DEV)) if affine else (None, None)
+    red0 = hip.conv3d_k1_head_dgrad_inbwd(dlc, w, dx0, cin, cout, yc, stats, gamma, beta, 0.1, 1e-5, dg0, db0, False)
+    dw = torch.full((cout, cin), 0.25, device=DEV)
+    red1 = hip.conv3d_k1_head_bwd_fused(dlc, w, dx1, cin, cout, yc, stats, gamma, beta, 0.1, 1e-5, dw, True, dg1, db1, False)
+    assert torch.equal(dx0, dx1)
+    assert torch.allclose(red0, red1, rtol=1e-5, atol=1e-5 * float(red0.abs().max()))
+    if affine:
+        assert torch.allclose(dg0, dg1, rtol=1e-5, atol=1e-5 * float(dg0.abs().max()))
+    dw_ref = torch.einsum("ndhwk,ndhwc->kc", dlc[..., :cout].float(), act.float()) + 0.25
+    tol = 2e-4 if dtype == torch.float32 else 2e-3
+    assert float((dw - dw_ref).abs().max()) / float(dw_ref.abs().max()) < tol
