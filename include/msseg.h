@@ -166,6 +166,17 @@ int msseg_deconv_k2s2_bwd_data_inbwd(const void* dy, long long lddy, const void*
                                      const void* act, long long ldact, const float* fwd_stats, float slope, float eps,
                                      float* red, float* dgamma, float* dbeta, int accumulate, void* scratch,
                                      size_t scratch_bytes, int dtype, msseg_stream_t stream);
+/* Input gradient of ConvTranspose3d k2 s2 with everything the pass over dy can produce: dx, optionally (yraw != NULL) the
+ * InstanceNorm-backward sums red[N][Cin][2] (+ dgamma / dbeta) of the layer that receives dx, and optionally
+ * (dbias != NULL) the bias gradient dbias[Cout] (+)= sum over all fine voxels of dy.  bf16 layers with Cin in {32, 64},
+ * Cout = 32 run on the register-resident-weight kernel (deconv_k2s2.hip): one read of dy, no statistics / channel-sum
+ * passes; other shapes fall back to the implicit-GEMM kernel plus a channel-sum pass. */
+int msseg_deconv_k2s2_bwd_fused(const void* dy, long long lddy, const void* wp, void* dx, long long lddx, int N,
+                                int D, int H, int W, int Cin, int Cout, const void* yraw, long long ldyraw,
+                                const void* act, long long ldact, const float* fwd_stats, float slope, float eps,
+                                float* red, float* dgamma, float* dbeta, int accumulate, float* dbias, int dbias_accumulate,
+                                void* scratch, size_t scratch_bytes, int dtype, msseg_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradients (fp32 output in the torch parameter layout; deterministic two-stage reduction).

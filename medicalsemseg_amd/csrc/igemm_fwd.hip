@@ -998,6 +998,8 @@ int msseg_deconv_k2s2_fwd(const void* x, long long ldx, const void* wp, const fl
     if (Cin % (16 / esz) || Cout % 4) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2: Cin %% %d and Cout %% 4 must be 0", 16 / esz);
     const long long NV = (long long)N * D * H * W;
     if (NV < 1 || NV > 0x7fffffffLL / 8) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2: bad voxel count");
+    if (msseg_deconv2_fast_eligible(dtype, Cin, Cout, x, ldx, y, ldy, bias))
+        return msseg_deconv2_fwd_launch(x, ldx, wp, bias, y, ldy, N, D, H, W, Cin, Cout, (hipStream_t)stream);
     IgemmParams p{};
     p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy;
     p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = Cin; p.M = 8 * Cout;
@@ -1014,6 +1016,9 @@ int msseg_deconv_k2s2_bwd_data(const void* dy, long long lddy, const void* wp, v
     if (Cout % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_data: Cout %% %d must be 0", 16 / esz);
     const long long NV = (long long)N * D * H * W;
     if (NV < 1 || NV > 0x7fffffffLL / 8) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_data: bad voxel count");
+    if (msseg_deconv2_fast_eligible(dtype, Cin, Cout, dx, lddx, dy, lddy, nullptr))
+        return msseg_deconv2_bwd_launch(dy, lddy, wp, dx, lddx, N, D, H, W, Cin, Cout, nullptr, 0, nullptr, 0, nullptr, 0.f, 0.f,
+                                        nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, (hipStream_t)stream);
     IgemmParams p{};
     p.x = dy; p.ldx = lddy; p.wp = wp; p.bias = nullptr; p.y = dx; p.ldy = lddx;
     p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = 8 * Cout; p.M = Cin;
@@ -1066,26 +1071,56 @@ int msseg_conv3d_k1_dgrad_inbwd(const void* dy, long long lddy, const void* wp, 
                               : launch_flat<bf16_t, SRC_DIRECT, EPI_STORE>(p, (hipStream_t)stream);
 }
 
+int msseg_deconv_k2s2_bwd_fused(const void* dy, long long lddy, const void* wp, void* dx, long long lddx, int N,
+                                int D, int H, int W, int Cin, int Cout, const void* yraw, long long ldyraw,
+                                const void* act, long long ldact, const float* fwd_stats, float slope, float eps,
+                                float* red, float* dgamma, float* dbeta, int accumulate, float* dbias, int dbias_accumulate,
+                                void* scratch, size_t scratch_bytes, int dtype, msseg_stream_t stream) {
+    const int esz = dtype == MSSEG_F32 ? 4 : 2;
+    int rc = check_common(dy, lddy, wp, dx, lddx, dtype, esz);
+    if (rc) return rc;
+    if (Cout % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_fused: Cout %% %d must be 0", 16 / esz);
+    const long long S = (long long)D * H * W;
+    if ((long long)N * S > 0x7fffffffLL / 8) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_fused: bad voxel count");
+    if (yraw) {
+        if (!act || !fwd_stats || !red) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_fused: yraw needs act, fwd_stats and red");
+        if (N > MSSEG_STATS_NMAX) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_fused: fused sums need N <= %d", MSSEG_STATS_NMAX);
+    }
+    if (msseg_deconv2_fast_eligible(dtype, Cin, Cout, dx, lddx, dy, lddy, nullptr) &&
+        (!yraw || ((ldyraw % 4) == 0 && (ldact % 4) == 0 && ((uintptr_t)yraw & 7) == 0 && ((uintptr_t)act & 7) == 0)))
+        return msseg_deconv2_bwd_launch(dy, lddy, wp, dx, lddx, N, D, H, W, Cin, Cout, yraw, ldyraw, act, ldact, fwd_stats,
+                                        slope, eps, red, dgamma, dbeta, accumulate, dbias, dbias_accumulate, scratch,
+                                        scratch_bytes, (hipStream_t)stream);
+    // generic path: the implicit-GEMM input gradient (with or without the fused sums) + a channel-sum pass for the bias
+    if (yraw) {
+        IgemmParams p{};
+        p.x = dy; p.ldx = lddy; p.wp = wp; p.bias = nullptr; p.y = dx; p.ldy = lddx;
+        p.K = 8 * Cout; p.M = Cin;
+        p.OD = D; p.OH = H; p.OW = W; p.creal = Cout;
+        rc = flat_inbwd_common(p, N, S, Cin, yraw, ldyraw, act, ldact, fwd_stats, slope, eps, red, dgamma, dbeta, accumulate,
+                               scratch, scratch_bytes, esz, "deconv_k2s2_bwd_fused");
+        if (rc) return rc;
+        rc = dtype == MSSEG_F32 ? launch_flat<float, SRC_DECONV_BWD, EPI_STORE>(p, (hipStream_t)stream)
+                                : launch_flat<bf16_t, SRC_DECONV_BWD, EPI_STORE>(p, (hipStream_t)stream);
+    } else {
+        rc = msseg_deconv_k2s2_bwd_data(dy, lddy, wp, dx, lddx, N, D, H, W, Cin, Cout, dtype, stream);
+    }
+    if (rc) return rc;
+    if (dbias)
+        return msseg_channel_sum(dy, lddy, dbias, 8 * (long long)N * S, Cout, dbias_accumulate, scratch, scratch_bytes, dtype,
+                                 stream);
+    return MSSEG_OK;
+}
+
 int msseg_deconv_k2s2_bwd_data_inbwd(const void* dy, long long lddy, const void* wp, void* dx, long long lddx, int N,
                                      int D, int H, int W, int Cin, int Cout, const void* yraw, long long ldyraw,
                                      const void* act, long long ldact, const float* fwd_stats, float slope, float eps,
                                      float* red, float* dgamma, float* dbeta, int accumulate, void* scratch,
                                      size_t scratch_bytes, int dtype, msseg_stream_t stream) {
-    const int esz = dtype == MSSEG_F32 ? 4 : 2;
-    int rc = check_common(dy, lddy, wp, dx, lddx, dtype, esz);
-    if (rc) return rc;
-    if (Cout % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_data_inbwd: Cout %% %d must be 0", 16 / esz);
-    const long long S = (long long)D * H * W;
-    if ((long long)N * S > 0x7fffffffLL / 8) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_data_inbwd: bad voxel count");
-    IgemmParams p{};
-    p.x = dy; p.ldx = lddy; p.wp = wp; p.bias = nullptr; p.y = dx; p.ldy = lddx;
-    p.K = 8 * Cout; p.M = Cin;
-    p.OD = D; p.OH = H; p.OW = W; p.creal = Cout;
-    rc = flat_inbwd_common(p, N, S, Cin, yraw, ldyraw, act, ldact, fwd_stats, slope, eps, red, dgamma, dbeta, accumulate,
-                           scratch, scratch_bytes, esz, "deconv_k2s2_bwd_data_inbwd");
-    if (rc) return rc;
-    return dtype == MSSEG_F32 ? launch_flat<float, SRC_DECONV_BWD, EPI_STORE>(p, (hipStream_t)stream)
-                              : launch_flat<bf16_t, SRC_DECONV_BWD, EPI_STORE>(p, (hipStream_t)stream);
+    if (!yraw || !act || !fwd_stats || !red) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_bwd_data_inbwd: null pointer");
+    return msseg_deconv_k2s2_bwd_fused(dy, lddy, wp, dx, lddx, N, D, H, W, Cin, Cout, yraw, ldyraw, act, ldact, fwd_stats,
+                                       slope, eps, red, dgamma, dbeta, accumulate, nullptr, 0, scratch, scratch_bytes, dtype,
+                                       stream);
 }
 
 }  // extern "C"

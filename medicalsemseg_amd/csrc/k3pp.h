@@ -70,3 +70,14 @@ bool msseg_stem_eligible(int dtype, int Cin, int Cout, int k, int s, int pd, lon
 int msseg_stem_fwd_launch(const StemParams& p, hipStream_t stream);
 int msseg_stem_wgrad_grid(const StemWgParams& p);
 int msseg_stem_wgrad_launch(const StemWgParams& p, int gx, hipStream_t stream);
+
+// ---- ConvTranspose3d k2 s2, register-resident weights (deconv_k2s2.hip) ----
+bool msseg_deconv2_fast_eligible(int dtype, int Cin, int Cout, const void* coarse, long long ldc, const void* fine,
+                                 long long ldf, const float* bias);
+int msseg_deconv2_fwd_launch(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy, int N,
+                             int D, int H, int W, int Cin, int Cout, hipStream_t stream);
+int msseg_deconv2_bwd_launch(const void* dy, long long lddy, const void* wp, void* dx, long long lddx, int N, int D, int H,
+                             int W, int Cin, int Cout, const void* yraw, long long ldyraw, const void* act, long long ldact,
+                             const float* fwd_stats, float slope, float eps, float* red, float* dgamma, float* dbeta,
+                             int accumulate, float* dbias, int dbias_accumulate, void* scratch, size_t scratch_bytes,
+                             hipStream_t stream);

@@ -42,6 +42,8 @@ SIGNATURES = {
                                      _vp, _vp, _i, _vp, _sz, _i, _vp], _i),
     "msseg_deconv_k2s2_bwd_data_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll, _vp, _f, _f,
                                           _vp, _vp, _vp, _i, _vp, _sz, _i, _vp], _i),
+    "msseg_deconv_k2s2_bwd_fused": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll, _vp, _f, _f,
+                                     _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_k3s2_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_zero_stuff2": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_window_attention_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -435,6 +437,27 @@ def deconv_k2s2_bwd_data_inbwd(dy, wp, dx, cin, cout, yraw, act, fwd_stats, slop
                                                ld(yraw), _p(act), ld(act), _p(fwd_stats), slope, eps, _p(red),
                                                _p(dgamma), _p(dbeta), int(accumulate), _p(sc), sc.numel(), dt(dy),
                                                _stream()), "deconv_k2s2_bwd_data_inbwd")
+    return red
+
+
+def deconv_k2s2_bwd_fused(dy, wp, dx, cin, cout, next_norm=None, dbias=None, dbias_accumulate=False, dgamma=None, dbeta=None,
+                          accumulate=False):
+    """dx of ConvTranspose3d k2 s2; next_norm = (yraw, act, fwd_stats, slope, eps) of the layer that receives dx adds its
+    InstanceNorm-backward sums (returned as red[N][cin][2]); dbias (fp32 [cout]) receives the bias gradient."""
+    _need_gpu(dy, wp, dx)
+    N, D, H, W = dx.shape[:4]
+    red = None
+    yraw = act = stats = None
+    slope = eps = 0.0
+    if next_norm is not None:
+        yraw, act, stats, slope, eps = next_norm
+        red = torch.empty(N, cin, 2, dtype=torch.float32, device=dy.device)
+    sc = scratch(dy.device)
+    _ck(lib().msseg_deconv_k2s2_bwd_fused(_p(dy), ld(dy), _p(wp), _p(dx), ld(dx), N, D, H, W, cin, cout, _p(yraw),
+                                          ld(yraw) if yraw is not None else 0, _p(act), ld(act) if act is not None else 0,
+                                          _p(stats), slope, eps, _p(red), _p(dgamma), _p(dbeta), int(accumulate), _p(dbias),
+                                          int(dbias_accumulate), _p(sc), sc.numel(), dt(dy), _stream()),
+        "deconv_k2s2_bwd_fused")
     return red
 
 

@@ -404,29 +404,30 @@ class Deconv2:
 
     def bwd(self, x, dy, need_dx=True, next_norm=None):
         """next_norm = (InstNormAct, yraw, stats, act) of the layer whose activation `x` is: its InstanceNorm-backward sums
-        are fused into the input-gradient kernel; returns (dx, red)."""
+        are fused into the input-gradient kernel; returns (dx, red).  The bias gradient comes out of the same pass."""
         dtype = x.dtype
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
             WGRAD_SIDE.run(lambda: hip.deconv_k2s2_wgrad(x, dy, g, self.cin, self.cout, acc), x, dy)
-        if self.b is not None and self.b.requires_grad:
-            g, acc = _grad_buf(self.b)
-            hip.channel_sum(dy, g, acc)
+        want_db = self.b is not None and self.b.requires_grad
         if not need_dx:
+            if want_db:
+                g, acc = _grad_buf(self.b)
+                hip.channel_sum(dy, g, acc)
             return None
         wp = self.cache.get(self.w, dtype, "d", lambda: hip.pack_deconv(self.w.detach(), dtype, bwd=True))
         dx = torch.empty_like(x, memory_format=torch.contiguous_format)
+        db, dbacc = _grad_buf(self.b) if want_db else (None, False)
+        nn_ = None
+        dg = dbt = None
+        nacc = False
         if next_norm is not None:
             nrm, yraw, stats, act = next_norm
             if dy.shape[0] <= 8 and self.cin % 4 == 0:
-                dg, db, acc = _norm_grad_bufs(nrm)
-                red = hip.deconv_k2s2_bwd_data_inbwd(dy, wp, dx, self.cin, self.cout, yraw, act, stats, nrm.slope, nrm.eps,
-                                                     dg, db, acc)
-                return dx, red
-            hip.deconv_k2s2_bwd_data(dy, wp, dx, self.cin, self.cout)
-            return dx, None
-        hip.deconv_k2s2_bwd_data(dy, wp, dx, self.cin, self.cout)
-        return dx
+                dg, dbt, nacc = _norm_grad_bufs(nrm)
+                nn_ = (yraw, act, stats, nrm.slope, nrm.eps)
+        red = hip.deconv_k2s2_bwd_fused(dy, wp, dx, self.cin, self.cout, nn_, db, dbacc, dg, dbt, nacc)
+        return (dx, red) if next_norm is not None else dx
 
 
 class InstNormAct:

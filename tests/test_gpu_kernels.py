@@ -169,7 +169,9 @@ def test_conv3d_stem(cout, sp, N):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cin,cout,sp", [(32, 32, (8, 8, 8)), (256, 128, (3, 3, 3)), (96, 48, (6, 6, 6)), (48, 48, (4, 6, 10))])
+@pytest.mark.parametrize("cin,cout,sp", [(32, 32, (8, 8, 8)), (256, 128, (3, 3, 3)), (96, 48, (6, 6, 6)), (48, 48, (4, 6, 10)),
+                                         # register-resident-weight kernels (bf16): ragged W segments, both channel counts
+                                         (64, 32, (6, 7, 9)), (32, 32, (5, 6, 20)), (64, 32, (3, 4, 33))])
 def test_deconv_k2s2(dtype, cin, cout, sp):
     from medicalsemseg_amd.layers import Deconv2
     dev = _dev()
@@ -706,3 +708,42 @@ def test_conv3d_k1_head_norm_fused_fwd_bwd(dtype, cin, cout, affine):
     dw_ref = torch.einsum("ndhwk,ndhwc->kc", dlc[..., :cout].float(), act.float()) + 0.25
     tol = 2e-4 if dtype == torch.float32 else 2e-3
     assert float((dw - dw_ref).abs().max()) / float(dw_ref.abs().max()) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,sp,N", [(32, 32, (6, 7, 9), 2), (64, 32, (4, 5, 18), 3), (48, 48, (4, 4, 6), 2)])
+def test_deconv_bwd_fused_sums_and_bias(dtype, cin, cout, sp, N):
+    """transposed-conv input gradient with the receiving layer's InstanceNorm-backward sums and the bias gradient from the
+    same pass == input gradient + separate reduction passes (bf16 32/64 -> 32: the register-resident-weight kernel)"""
+    from medicalsemseg_amd import hip
+    from medicalsemseg_amd.layers import Deconv2, InstNormAct
+    dev = _dev()
+    yraw = cl(gen(N, cin, *sp, seed=1) * 1.5 + 0.3, dtype, dev)
+    w = torch.nn.Parameter(gen(cin, cout, 2, 2, 2, seed=2, scale=cin ** -0.5).to(dev))
+    b = torch.nn.Parameter(gen(cout, seed=6).to(dev))
+    fine = tuple(2 * v for v in sp)
+    dy = cl(gen(N, cout, *fine, seed=3), dtype, dev)
+    ga = torch.nn.Parameter((gen(cin, seed=4) * 0.2 + 1).to(dev))
+    be = torch.nn.Parameter((gen(cin, seed=5) * 0.2).to(dev))
+    nrm = InstNormAct(ga, be, 0.1)
+    act, stats = nrm.fwd(yraw)
+    op = Deconv2(w, b)
+    w.requires_grad_(False)
+    # reference: plain input gradient, separate InstanceNorm-backward reduce, separate channel sum
+    wp = hip.pack_deconv(w.detach(), dtype, bwd=True)
+    dx_ref = torch.empty_like(act)
+    hip.deconv_k2s2_bwd_data(dy, wp, dx_ref, cin, cout)
+    dyraw_ref = nrm.bwd(yraw, stats, act, dx_ref)
+    g_ref, b_ref = ga.grad.clone(), be.grad.clone()
+    ga.grad = be.grad = None
+    db_ref = dy.float().sum(dim=(0, 1, 2, 3))
+    # fused
+    dx, red = op.bwd(act, dy, True, next_norm=(nrm, yraw, stats, act))
+    assert red is not None
+    dyraw = nrm.bwd(yraw, stats, act, dx, red=red)
+    assert torch.equal(dx, dx_ref)
+    tol = 2e-4 if dtype == torch.float32 else 2e-3
+    sc = float(dyraw_ref.float().abs().max())
+    assert float((dyraw.float() - dyraw_ref.float()).abs().max()) / sc < tol
+    for a, bb, nm in ((ga.grad, g_ref, "dgamma"), (be.grad, b_ref, "dbeta"), (b.grad, db_ref, "dbias")):
+        assert float((a - bb).abs().max()) / (float(bb.abs().max()) + 1e-6) < 5e-4, nm
