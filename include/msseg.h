@@ -357,6 +357,20 @@ int msseg_sw_blend_batch(const void* win, long long ldw, int dtype, const float*
                          float* cnt, long long cnt_bstride, const int* table, int nwin, int C, int VD, int VH, int VW,
                          int RD, int RH, int RW, msseg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Post-inference (the step right after the path).
+ * argmax_u8: out[v] = first arg max over c of logits[c][v] (NCDHW fp32, one sample) -- engine/test.py:140-141
+ *            (softmax is monotonic, so it is skipped).
+ * resample_nearest_u8: scipy.ndimage.zoom(order=0, prefilter=False) of a uint8 label map to (TD, TH, TW) --
+ *            utils/misc.py:420-425; coordinates in double exactly as scipy forms them.
+ * majority_vote_u8: labels [F][V] -> out[V]; votes[c] = #folds with label c for c >= 1, votes[0] = 1, first maximum --
+ *            majority_vote.py:23-37.
+ * ------------------------------------------------------------------------------------------- */
+int msseg_argmax_u8(const float* logits, int C, long long V, uint8_t* out, msseg_stream_t stream);
+int msseg_resample_nearest_u8(const uint8_t* src, int SD, int SH, int SW, uint8_t* dst, int TD, int TH, int TW,
+                              msseg_stream_t stream);
+int msseg_majority_vote_u8(const uint8_t* labels, int F, long long V, int C, uint8_t* out, msseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,16 +245,12 @@ __global__ __launch_bounds__(DC_THREADS, 2) void deconv2_bwd_kernel(const Dc2Par
     }
 }
 
-// out[c] (+)= sum of R rows (fixed order)
+// out[c] (+)= sum of R rows (fixed order): float4 columns x row slots, slots added through LDS
 __global__ __launch_bounds__(256) void dc2_bias_finalize_kernel(const float* rows, int R, int C, float* out, int accumulate) {
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s0 = 0.f, s1 = 0.f;
-        int i = 0;
-        for (; i + 1 < R; i += 2) { s0 += rows[(long long)i * C + c]; s1 += rows[(long long)(i + 1) * C + c]; }
-        if (i < R) s0 += rows[(long long)i * C + c];
-        const float t = s0 + s1;
-        out[c] = accumulate ? out[c] + t : t;
-    }
+    __shared__ __attribute__((aligned(16))) float fin[256 * 4 + 256];
+    block_rows_sum<256>(rows, R, C, fin);
+    const float* tot = fin + 256 * 4;
+    for (int c = threadIdx.x; c < C; c += 256) out[c] = accumulate ? out[c] + tot[c] : tot[c];
 }
 
 int grid_x(long long groups) {

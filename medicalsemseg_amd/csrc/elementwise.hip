@@ -779,7 +779,8 @@ __global__ __launch_bounds__(RED_THREADS) void head_dgrad_inbwd_kernel(const Hea
             for (int k = 0; k < (DW ? 4 : 1); ++k) gw[k][e] = 0.f;
         }
         if (act && rl < p.rows_par) {
-#pragma unroll 4
+            constexpr int UNR = DW ? 2 : 4;   // the weight-gradient variant carries 32 more accumulators: stay under 256 VGPRs
+#pragma unroll UNR
             for (long long r = r0 + rl; r < r1; r += p.rows_par) {
                 Chunk<T> xc, dc, o;
                 xc.load(xn + r * p.ldx + gg * WD);

@@ -1,6 +1,9 @@
 """Evaluation / test-time inference: mirrors ``/root/reference/engine/test.py`` (``eval_model`` :15-94,
-``test_model`` :96-173).  Hausdorff95 and the NIfTI dump are outside the hot path: results
-are returned / saved as ``.npy`` label maps instead of NIfTI (nibabel is not available here)."""
+``test_model`` :96-173).  The label map is formed on the device (``msseg_argmax_u8``: the arg max of the blended logits,
+the reference's softmax is monotonic) and resampled to the original grid with ``msseg_resample_nearest_u8`` (the
+reference's ``resample_3d`` = scipy order-0 zoom, ``utils/misc.py:420-425``); only uint8 maps cross PCIe.  Hausdorff95
+and NIfTI writing are outside the hot path (nibabel is not available): maps are saved as ``.npy`` under the reference's
+directory layout."""
 from __future__ import annotations
 
 import os
@@ -8,34 +11,43 @@ import os
 import numpy as np
 import torch
 
+from .. import hip
 from ..utils import misc
 from .train import _metric_update
 from .utils import sliding_window_inference
 
 
+def label_map(outputs: torch.Tensor) -> torch.Tensor:
+    """logits [1, C, D, H, W] -> uint8 [D, H, W] on the device (engine/test.py:140-141)"""
+    return hip.argmax_u8(outputs[0].float().contiguous())
+
+
 def eval_model(inferer, model, data_loader, criterion, device, cfg, log_writer=None):
-    """`inferer(inputs, network)` -> logits; pass ``functools.partial``-style callables or None for the built-in
-    sliding window with the validation settings."""
+    """`inferer(inputs=..., network=...)` -> logits (MONAI SlidingWindowInferer call convention, engine/test.py:47), or
+    None for the built-in sliding window with the validation settings.  Returns {'eval/<meter>': global average}."""
     model.eval()
     metric_logger = misc.MetricLogger(delimiter="  ")
-    header = "Evaluation:"
+    for name in ["loss", "mDice"] + ["class" + str(c) + "Dice" for c in range(cfg.output_dim)]:
+        metric_logger.add_meter(name, misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    header = "Evaluation starting"
     for data_iter_step, batch in enumerate(metric_logger.log_every(data_loader, 1, header)):
         inputs = batch["image"].to(device, non_blocking=True)
         labels = batch["label"].to(device, non_blocking=True)
         aff_xyz = misc.get_affine_xyz(batch["image_meta_dict"]["original_affine"]).float().to(device)
+        img_name = os.path.split(str(batch["image_meta_dict"]["filename_or_obj"][0]))[-1]
         with torch.no_grad():
             if inferer is None:
                 outputs = sliding_window_inference(inputs, aff_xyz, cfg.vol_size, cfg.batch_size_val, model,
                                                    overlap=cfg.val_infer_overlap, mode="gaussian")
             else:
-                outputs = inferer(inputs=inputs, network=lambda w: model((w, None, aff_xyz)))
+                # the reference hands the bare module to MONAI's inferer, which feeds it a bare window tensor
+                outputs = inferer(inputs=inputs, network=lambda w, *a, **k: model((w, None, aff_xyz)))
             loss = criterion(outputs, labels)
         mDice = _metric_update(metric_logger, criterion, outputs, labels, cfg.output_dim)
         metric_logger.update(loss=loss.item(), mDice=mDice.item())
         if getattr(cfg, "save_eval_output", False) and cfg.output_dir:
             os.makedirs(cfg.output_dir, exist_ok=True)
-            np.save(os.path.join(cfg.output_dir, f"eval_{data_iter_step}.npy"),
-                    outputs.argmax(1).to(torch.uint8).cpu().numpy())
+            np.save(os.path.join(cfg.output_dir, "pred_" + img_name + ".npy"), label_map(outputs).cpu().numpy())
     metric_logger.synchronize_between_processes()
     print("Evaluation averaged stats:", metric_logger.log_all_average())
     return {"eval/" + k: meter.global_avg for k, meter in metric_logger.meters.items()}
@@ -47,11 +59,33 @@ def test_model(model, data_loader, device, cfg, log_writer=None):
     for i, batch in enumerate(data_loader):
         inputs = batch["image"].to(device, non_blocking=True)
         aff_xyz = misc.get_affine_xyz(batch["image_meta_dict"]["original_affine"]).float().to(device)
+        img_name = os.path.split(str(batch["image_meta_dict"]["filename_or_obj"][0]))[-1].split("img")[-1]
         with torch.no_grad():
             outputs = sliding_window_inference(inputs, aff_xyz, cfg.vol_size, cfg.batch_size_val, model,
                                                overlap=cfg.val_infer_overlap, mode="gaussian", cval=air_cval)
-        seg = outputs.softmax(1).argmax(1).to(torch.uint8).cpu().numpy()
-        if cfg.output_dir:
-            os.makedirs(cfg.output_dir, exist_ok=True)
-            np.save(os.path.join(cfg.output_dir, f"test_{i}.npy"), seg)
+        seg = label_map(outputs)
+        seg_rs = None
+        if getattr(cfg, "t_voxel_spacings", None):
+            target = None
+            for t in batch.get("image_transforms", []):
+                if t["class"][0] == "Spacingd":
+                    target = [int(v[0]) if hasattr(v, "__len__") else int(v) for v in t["orig_size"]]
+            if target is not None:
+                seg_rs = hip.resample_nearest_u8(seg, target)
+        if getattr(cfg, "save_eval_output", False) and cfg.output_dir:
+            out_dir = os.path.join(cfg.output_dir, "test_output", "Fold" + str(getattr(cfg, "cv_fold", 0)))
+            os.makedirs(os.path.join(out_dir, "pred"), exist_ok=True)
+            np.save(os.path.join(out_dir, "pred", img_name + ".npy"), seg.cpu().numpy())
+            if seg_rs is not None:
+                os.makedirs(os.path.join(out_dir, "rs"), exist_ok=True)
+                np.save(os.path.join(out_dir, "rs", img_name + ".npy"), seg_rs.cpu().numpy())
     return None
+
+
+def majority_vote(fold_maps, n_classes: int) -> torch.Tensor:
+    """fold_maps: sequence of uint8 [D, H, W] label maps (one per fold) -> voted uint8 map on the device
+    (/root/reference/majority_vote.py:23-37)"""
+    stack = torch.stack([torch.as_tensor(m, dtype=torch.uint8) for m in fold_maps]).contiguous()
+    if not stack.is_cuda:
+        stack = stack.cuda()
+    return hip.majority_vote_u8(stack, n_classes)

@@ -94,6 +94,9 @@ SIGNATURES = {
     "msseg_sw_blend": ([_vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_sw_normalize": ([_vp, _vp, _i, _ll, _vp], _i),
     "msseg_sw_gather": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "msseg_argmax_u8": ([_vp, _i, _ll, _vp, _vp], _i),
+    "msseg_resample_nearest_u8": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _vp], _i),
+    "msseg_majority_vote_u8": ([_vp, _i, _ll, _i, _vp, _vp], _i),
     "msseg_sw_gather_batch": ([_vp, _ll, _vp, _ll, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
     "msseg_sw_blend_batch": ([_vp, _ll, _i, _vp, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
 }
@@ -798,6 +801,39 @@ def sw_blend_batch(win, imp, out, cnt, table, nwin, channels_last_ld=0):
     RD, RH, RW = imp.shape
     _ck(lib().msseg_sw_blend_batch(_p(win), channels_last_ld, dt(win), _p(imp), _p(out), out.stride(0), _p(cnt),
                                    cnt.stride(0), _p(table), nwin, Cc, VD, VH, VW, RD, RH, RW, _stream()), "sw_blend_batch")
+
+
+# --------------------------------------------------------------------------------------------
+# post-inference
+# --------------------------------------------------------------------------------------------
+def argmax_u8(logits: torch.Tensor) -> torch.Tensor:
+    """logits [C, D, H, W] fp32 (one sample, contiguous) -> uint8 [D, H, W], first maximum over C"""
+    _need_gpu(logits)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 4
+    out = torch.empty(logits.shape[1:], dtype=torch.uint8, device=logits.device)
+    _ck(lib().msseg_argmax_u8(_p(logits), logits.shape[0], out.numel(), _p(out), _stream()), "argmax_u8")
+    return out
+
+
+def resample_nearest_u8(src: torch.Tensor, target_size) -> torch.Tensor:
+    """uint8 [D, H, W] -> uint8 target_size, scipy.ndimage.zoom(order=0) semantics"""
+    _need_gpu(src)
+    assert src.dtype == torch.uint8 and src.is_contiguous() and src.dim() == 3
+    td, th, tw = (int(v) for v in target_size)
+    out = torch.empty(td, th, tw, dtype=torch.uint8, device=src.device)
+    _ck(lib().msseg_resample_nearest_u8(_p(src), src.shape[0], src.shape[1], src.shape[2], _p(out), td, th, tw, _stream()),
+        "resample_nearest_u8")
+    return out
+
+
+def majority_vote_u8(labels: torch.Tensor, n_classes: int) -> torch.Tensor:
+    """labels [F, D, H, W] uint8 (one label map per fold) -> uint8 [D, H, W]"""
+    _need_gpu(labels)
+    assert labels.dtype == torch.uint8 and labels.is_contiguous() and labels.dim() >= 2
+    out = torch.empty(labels.shape[1:], dtype=torch.uint8, device=labels.device)
+    _ck(lib().msseg_majority_vote_u8(_p(labels), labels.shape[0], out.numel(), n_classes, _p(out), _stream()),
+        "majority_vote_u8")
+    return out
 
 
 # --------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 sys.path.insert(0, REPO)
-from tests.golden_util import det_fill_, det_tensor  # noqa: E402
+from tests.golden_util import SW_CASES, det_fill_, det_tensor, sw_predictor  # noqa: E402
 
 
 def _install_import_shims():
@@ -196,6 +196,64 @@ def gen_unetr_conv_blocks():
     _save("unetr_blocks.npz", **out)
 
 
+def gen_sliding_window_loop():
+    """The reference's OWN loop (engine/utils.py:19-159: padding, window order, `centers`, blend, final slicing) run with the
+    four MONAI helper names it imports bound in memory to oracle/sliding_window.py's restatements (MONAI is absent)."""
+    import enum
+    from oracle import sliding_window as osw
+
+    class BlendMode(enum.Enum):
+        CONSTANT = "constant"
+        GAUSSIAN = "gaussian"
+
+    class PytorchPadMode(enum.Enum):
+        CONSTANT = "constant"
+        REFLECT = "reflect"
+        REPLICATE = "replicate"
+        CIRCULAR = "circular"
+
+    def look_up_option(opt, supported):
+        return opt if isinstance(opt, supported) else supported(opt)
+
+    mods = {n: types.ModuleType(n) for n in ["monai.data", "monai.data.utils", "monai.inferers", "monai.inferers.utils"]}
+    mods["monai.data.utils"].compute_importance_map = lambda ps, mode="constant", sigma_scale=0.125, device=None: \
+        osw.compute_importance_map(ps, getattr(mode, "value", mode), sigma_scale)
+    mods["monai.data.utils"].dense_patch_slices = osw.dense_patch_slices
+    mods["monai.data.utils"].get_valid_patch_size = osw.get_valid_patch_size
+    mods["monai.inferers.utils"]._get_scan_interval = osw.get_scan_interval
+    sys.modules.update(mods)
+    mu = sys.modules["monai.utils"]
+    mu.BlendMode, mu.PytorchPadMode, mu.look_up_option = BlendMode, PytorchPadMode, look_up_option
+    mu.fall_back_tuple = osw.fall_back_tuple
+    mu.optional_import = lambda *a, **k: (None, False)
+    import importlib
+    ref_utils = importlib.import_module("engine.utils")
+    out = {}
+    for tag, vol, roi, sb, ov, mode, cval in SW_CASES:
+        x = det_tensor("sw_x_" + tag, vol)
+        aff = det_tensor("sw_aff_" + tag, (vol[0], 3))
+        y = ref_utils.sliding_window_inference(x, aff, roi, sb, sw_predictor, overlap=ov, mode=mode, cval=cval)
+        out["out_" + tag] = y
+    _save("sliding_window_ref.npz", **out)
+
+
+def gen_layers():
+    """the reference's vendored DropPath (models/layers/drop_path.py:15-45) and trunc_normal_ (weight_init.py:17-64) under
+    fixed CPU seeds"""
+    from models.layers.drop_path import DropPath
+    from models.layers.weight_init import trunc_normal_
+    x = det_tensor("dp_x", (16, 5, 7))
+    dp = DropPath(0.2).train()
+    torch.manual_seed(7)
+    y = dp(x)
+    dp_eval = DropPath(0.2).eval()(x)
+    torch.manual_seed(3)
+    t = trunc_normal_(torch.empty(64, 48), std=0.02)
+    torch.manual_seed(4)
+    t2 = trunc_normal_(torch.empty(257), mean=0.5, std=1.0, a=-1.0, b=2.0)
+    _save("layers_ref.npz", dp_x=x, dp_y=y, dp_eval=dp_eval, tn=t, tn2=t2)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("needs /root/reference (build container only)")
@@ -208,6 +266,8 @@ def main():
     gen_encoder(ref)
     gen_lr_and_misc()
     gen_unetr_conv_blocks()
+    gen_sliding_window_loop()
+    gen_layers()
 
 
 if __name__ == "__main__":

@@ -158,3 +158,71 @@ def test_run_training_two_ranks_share_one_gpu_over_gloo(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     ck = torch.load(tmp_path / "checkpoint-1.pth", map_location="cpu", weights_only=True)
     assert ck["epoch"] == 1 and all(torch.isfinite(v).all() for v in ck["model"].values())
+
+
+def test_sliding_window_vs_reference_loop_golden(golden_dir):
+    """the product's loop (batched gather / blend kernels, generic-predictor path) against outputs of the REFERENCE's own
+    sliding_window_inference (/root/reference/engine/utils.py:19-159, tests/golden/sliding_window_ref.npz): padding,
+    non-cubic volumes, sw_batch_size 1 (centers quirk) and short last batches, overlap 0.25 / 0.5, both blend modes"""
+    from medicalsemseg_amd.engine.utils import sliding_window_inference
+    from tests.golden_util import SW_CASES, det_tensor, sw_predictor
+    g = np.load(os.path.join(golden_dir, "sliding_window_ref.npz"))
+    for tag, vol, roi, sb, ov, mode, cval in SW_CASES:
+        x = det_tensor("sw_x_" + tag, vol).to(DEV)
+        aff = det_tensor("sw_aff_" + tag, (vol[0], 3)).to(DEV)
+        y = sliding_window_inference(x, aff, roi, sb, sw_predictor, overlap=ov, mode=mode, cval=cval)
+        assert tuple(y.shape) == g["out_" + tag].shape, tag
+        np.testing.assert_allclose(y.cpu().numpy(), g["out_" + tag], rtol=1e-5, atol=1e-5, err_msg=tag)
+
+
+def test_eval_model_and_test_model_vs_oracle(tmp_path):
+    """engine.test.eval_model (built-in sliding window and a MONAI-style `inferer(inputs=, network=)`) and test_model
+    (device argmax -> uint8, nearest resample to the original grid, saved maps) against the CPU oracle pipeline"""
+    import functools
+    from medicalsemseg_amd.data import SyntheticLoader
+    from medicalsemseg_amd.engine.test import eval_model, majority_vote, test_model
+    from medicalsemseg_amd.engine.utils import sliding_window_inference as sw_hip
+    from medicalsemseg_amd.losses import DiceCELoss
+    from medicalsemseg_amd.utils.arguments import get_args
+    from oracle.losses import class_means_and_mdice, dice_ce_loss, dice_metric
+    from oracle.postproc import argmax_labels, resample_nearest
+    from oracle.sliding_window import sliding_window_inference as sw_ref
+    ref, net = _pair(out_ch=3)
+    cfg = get_args(f"--model UNetSmall --output_dim 3 --vol_size 32 --batch_size_val 2 --val_infer_overlap 0.5 "
+                   f"--save_eval_output --t_voxel_spacings --output_dir {tmp_path}".split())
+    loader = lambda: SyntheticLoader(2, 1, (48, 32, 64), 1, 3, seed=5, with_crop_info=False)   # noqa: E731
+    # oracle pipeline: loop + network + loss + hard Dice on the CPU
+    losses, mdices, maps = [], [], []
+    with torch.no_grad():
+        for b in loader():
+            aff = torch.ones(1, 3)
+            out = sw_ref(b["image"], aff, (32, 32, 32), 2, ref, overlap=0.5, mode="gaussian")
+            losses.append(float(dice_ce_loss(out, b["label"])))
+            mdices.append(float(class_means_and_mdice(*dice_metric(out, b["label"]))[1]))
+            maps.append(argmax_labels(out[0].numpy()))
+    crit = DiceCELoss()
+    r1 = eval_model(None, net, loader(), crit, torch.device(DEV), cfg)
+    inferer = lambda inputs, network: sw_hip(inputs, None, (32, 32, 32), 2, network, overlap=0.5, mode="gaussian")   # noqa: E731
+    r2 = eval_model(inferer, net, loader(), crit, torch.device(DEV), cfg)
+    for r in (r1, r2):
+        assert abs(r["eval/loss"] - np.mean(losses)) < 1e-4
+        assert abs(r["eval/mDice"] - np.mean(mdices)) < 1e-3
+    for i, m in enumerate(maps):     # saved label maps == oracle arg max (ties aside: fp32 logits differ by ~1e-5)
+        got = np.load(os.path.join(tmp_path, f"pred_synthetic_{i}_0.npy"))
+        assert got.dtype == np.uint8 and (got != m).mean() < 1e-4
+
+    class WithSpacing:    # the loader plus the Spacingd record test_model reads the original size from
+        def __iter__(self):
+            for b in loader():
+                b["image_transforms"] = [{"class": ["Spacingd"], "orig_size": [torch.tensor([60]), torch.tensor([41]), torch.tensor([70])]}]
+                yield b
+    assert test_model(net, WithSpacing(), torch.device(DEV), cfg) is None
+    out_dir = os.path.join(tmp_path, "test_output", "Fold0")
+    for i, m in enumerate(maps):
+        pred = np.load(os.path.join(out_dir, "pred", f"synthetic_{i}_0.npy"))
+        rs = np.load(os.path.join(out_dir, "rs", f"synthetic_{i}_0.npy"))
+        assert (pred != m).mean() < 1e-4
+        assert rs.shape == (60, 41, 70) and np.array_equal(rs, resample_nearest(pred, (60, 41, 70)))
+    voted = majority_vote([maps[0], maps[0], maps[1]], 3).cpu().numpy()
+    from oracle.postproc import majority_vote as mv_ref
+    assert np.array_equal(voted, mv_ref(np.stack([maps[0], maps[0], maps[1]]), 3))

@@ -114,3 +114,61 @@ def test_unetr_conv_blocks(golden_dir):
         t = F.conv3d(F.conv_transpose3d(x2, P["blk_dw"], P["blk_db"], stride=2), P["blk_cw"], P["blk_cb"], padding=1)
         t = torch.relu(t / np.sqrt(1.0 + 1e-5) * P["blk_bn_w"].view(1, -1, 1, 1, 1) + P["blk_bn_b"].view(1, -1, 1, 1, 1))
     _close(t, g["block_y"])
+
+
+def test_sliding_window_loop_vs_reference_loop(golden_dir):
+    """oracle/sliding_window.py against the reference's OWN loop (/root/reference/engine/utils.py:19-159, run by
+    oracle/gen_golden.py with the MONAI helper names bound to the oracle's restatements): padding, window order, the
+    relative `centers` (incl. the unsqueeze quirk at sw_batch_size 1), blend order and the final slicing"""
+    from oracle.sliding_window import sliding_window_inference
+    from tests.golden_util import SW_CASES, sw_predictor
+    g = _load(golden_dir, "sliding_window_ref.npz")
+    for tag, vol, roi, sb, ov, mode, cval in SW_CASES:
+        x = det_tensor("sw_x_" + tag, vol)
+        aff = det_tensor("sw_aff_" + tag, (vol[0], 3))
+        y = sliding_window_inference(x, aff, roi, sb, sw_predictor, overlap=ov, mode=mode, cval=cval)
+        assert tuple(y.shape) == g["out_" + tag].shape, tag
+        np.testing.assert_allclose(y.numpy(), g["out_" + tag], rtol=1e-6, atol=1e-6, err_msg=tag)
+
+
+def test_drop_path_and_trunc_normal_vs_reference_layers(golden_dir):
+    """the reference's vendored DropPath / trunc_normal_ under fixed CPU seeds: the oracle restatements and torch's own
+    trunc_normal_ (what the product's modules initialise with) reproduce them bit for bit"""
+    from oracle.layers import drop_path, trunc_normal_
+    g = _load(golden_dir, "layers_ref.npz")
+    x = torch.from_numpy(g["dp_x"])
+    torch.manual_seed(7)
+    y = drop_path(x, 0.2, training=True)
+    np.testing.assert_array_equal(y.numpy(), g["dp_y"])
+    np.testing.assert_array_equal(drop_path(x, 0.2, training=False).numpy(), g["dp_eval"])
+    kept = np.abs(g["dp_y"]).reshape(16, -1).max(1) > 0
+    assert 0 < kept.sum() < 16                      # the seed exercises both branches
+    np.testing.assert_allclose(g["dp_y"][kept], g["dp_x"][kept] / 0.8, rtol=1e-6)
+    torch.manual_seed(3)
+    np.testing.assert_array_equal(trunc_normal_(torch.empty(64, 48), std=0.02).numpy(), g["tn"])
+    torch.manual_seed(4)
+    np.testing.assert_array_equal(trunc_normal_(torch.empty(257), mean=0.5, std=1.0, a=-1.0, b=2.0).numpy(), g["tn2"])
+    torch.manual_seed(3)
+    np.testing.assert_array_equal(torch.nn.init.trunc_normal_(torch.empty(64, 48), std=0.02).numpy(), g["tn"])
+    assert np.abs(g["tn"]).max() <= 2.0 and abs(float(g["tn"].std()) - 0.02) < 2e-3
+    assert g["tn2"].min() >= -1.0 and g["tn2"].max() <= 2.0
+
+
+def test_postproc_oracle(golden_dir):
+    """nearest resample against the reference's resample_3d fixture and scipy's zoom; majority vote known answers"""
+    from scipy import ndimage
+    from oracle.postproc import argmax_labels, majority_vote, resample_nearest
+    g = _load(golden_dir, "resample.npz")
+    np.testing.assert_array_equal(resample_nearest(g["vol"], g["out"].shape), g["out"])
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        s, t = tuple(rng.integers(1, 20, 3)), tuple(rng.integers(1, 25, 3))
+        v = rng.integers(0, 5, s).astype(np.uint8)
+        ref = ndimage.zoom(v, tuple(float(a) / float(b) for a, b in zip(t, s)), order=0, prefilter=False)
+        if ref.shape == t:
+            np.testing.assert_array_equal(resample_nearest(v, t), ref)
+    # majority vote: a foreground class needs two votes to beat the background's initial one; ties -> lower class index
+    folds = np.array([[1, 1, 2, 0, 2], [1, 0, 2, 0, 1], [2, 0, 1, 0, 1], [0, 0, 1, 3, 2], [0, 0, 0, 3, 2]], dtype=np.uint8).reshape(5, 1, 1, 5)
+    np.testing.assert_array_equal(majority_vote(folds, 4).ravel(), [1, 0, 1, 3, 2])
+    x = rng.standard_normal((3, 4, 5, 6)).astype(np.float32)
+    np.testing.assert_array_equal(argmax_labels(x), x.argmax(0).astype(np.uint8))
