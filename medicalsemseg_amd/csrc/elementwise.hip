@@ -726,23 +726,23 @@ struct HeadFinArgs {
     const float* ws; int N, nblk, C, nper, Cout; float* red; float* dbeta; float* dgamma; float* dw; int acc_norm, acc_dw;
 };
 __global__ __launch_bounds__(256) void head_finalize_kernel(const HeadFinArgs a) {
-    const int L = a.C * a.nper;
+    __shared__ __attribute__((aligned(16))) float fin[256 * 4 + 64 * 6];
+    __shared__ float tot_n[64 * 6];
+    const int L = a.C * a.nper;      // <= 64 * 6 floats, a multiple of 4
+    for (int o = threadIdx.x; o < L; o += 256) tot_n[o] = 0.f;
+    for (int n = 0; n < a.N; ++n) {
+        block_rows_sum<256>(a.ws + (long long)n * a.nblk * L, a.nblk, L, fin);   // barriers inside
+        const float* t = fin + 256 * 4;
+        for (int o = threadIdx.x; o < L; o += 256) {
+            const int c = o / a.nper, k = o % a.nper;
+            if (k < 2) a.red[((long long)n * a.C + c) * 2 + k] = t[o];
+            tot_n[o] += t[o];
+        }
+        __syncthreads();
+    }
     for (int o = threadIdx.x; o < L; o += 256) {
         const int c = o / a.nper, k = o % a.nper;
-        float tot = 0.f;
-        for (int n = 0; n < a.N; ++n) {
-            const float* src = a.ws + (long long)n * a.nblk * L + o;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int b = 0;
-            for (; b + 3 < a.nblk; b += 4) {
-                s0 += src[(long long)b * L]; s1 += src[(long long)(b + 1) * L];
-                s2 += src[(long long)(b + 2) * L]; s3 += src[(long long)(b + 3) * L];
-            }
-            for (; b < a.nblk; ++b) s0 += src[(long long)b * L];
-            const float t = (s0 + s1) + (s2 + s3);
-            if (k < 2) a.red[((long long)n * a.C + c) * 2 + k] = t;
-            tot += t;
-        }
+        const float tot = tot_n[o];
         if (k == 0) { if (a.dbeta) a.dbeta[c] = a.acc_norm ? a.dbeta[c] + tot : tot; }
         else if (k == 1) { if (a.dgamma) a.dgamma[c] = a.acc_norm ? a.dgamma[c] + tot : tot; }
         else if (k - 2 < a.Cout && a.dw) a.dw[(k - 2) * a.C + c] = a.acc_dw ? a.dw[(k - 2) * a.C + c] + tot : tot;
@@ -1336,7 +1336,7 @@ static int head_bwd_impl(const void* dy, long long lddy, const float* w, void* d
     if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_dgrad_inbwd: bad dtype");
     if (int rc = scratch_ok(scratch, scratch_bytes, "conv3d_k1_head_dgrad_inbwd")) return rc;
     const int esz = dtype == MSSEG_F32 ? 4 : 2, epc = 16 / esz;
-    if (Cout < 1 || Cout > 4 || C < 1 || !vec_ok(yraw, ldyraw, C, esz) || !vec_ok(da, ldda, C, esz) ||
+    if (Cout < 1 || Cout > 4 || C < 1 || C > 64 || !vec_ok(yraw, ldyraw, C, esz) || !vec_ok(da, ldda, C, esz) ||
         (lddy % epc) || ((uintptr_t)dy & 15))
         MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1_head_dgrad_inbwd: needs <= 4 classes in 16-byte aligned gradient rows and "
                                  "16-byte channel chunks (C=%d, Cout=%d, lddy=%lld)", C, Cout, lddy);

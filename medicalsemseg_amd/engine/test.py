@@ -40,8 +40,10 @@ def eval_model(inferer, model, data_loader, criterion, device, cfg, log_writer=N
                 outputs = sliding_window_inference(inputs, aff_xyz, cfg.vol_size, cfg.batch_size_val, model,
                                                    overlap=cfg.val_infer_overlap, mode="gaussian")
             else:
-                # the reference hands the bare module to MONAI's inferer, which feeds it a bare window tensor
-                outputs = inferer(inputs=inputs, network=lambda w, *a, **k: model((w, None, aff_xyz)))
+                # the reference hands the bare module to MONAI's inferer, which feeds it a bare window tensor (the models
+                # want the (window, centers, affine) tuple: SURVEY.md M4); an inferer that already builds the tuple passes
+                outputs = inferer(inputs=inputs, network=lambda w, *a, **k: model(
+                    w if isinstance(w, (tuple, list)) else (w, None, aff_xyz)))
             loss = criterion(outputs, labels)
         mDice = _metric_update(metric_logger, criterion, outputs, labels, cfg.output_dim)
         metric_logger.update(loss=loss.item(), mDice=mDice.item())

@@ -364,7 +364,7 @@ class Conv1:
         kpad = dy_channels if dy_channels is not None else self.cout
         dyk = dy if dy_channels is None else dy[..., :kpad]
         epc = 16 // dy.element_size()
-        if (next_norm is not None and self.cout <= 4 and kpad >= 4 and self.cin % epc == 0 and hip.ld(dyk) % epc == 0
+        if (next_norm is not None and self.cout <= 4 and kpad >= 4 and self.cin <= 64 and self.cin % epc == 0 and hip.ld(dyk) % epc == 0
                 and dyk.data_ptr() % 16 == 0 and self.w.is_contiguous() and not os.environ.get("MSSEG_NO_HEAD_KERNEL")):
             # segmentation head: streaming kernel on the fp32 weight, with the receiving layer's backward sums
             nrm, yraw, stats, act = next_norm
