@@ -842,12 +842,6 @@ int msseg_conv3d_k3_kernel(int N, int D, int H, int W, int Cin, int Cout, int dt
         pp.N = N; pp.D = D; pp.H = H; pp.W = W; pp.K = Cin; pp.M = Cout;
         if ((Cin % 8) == 0 && (Cout % 4) == 0 && msseg_k3pp_eligible(pp)) return 3;
     }
-    if (dtype == MSSEG_BF16) {
-        K3ppParams pp{};
-        pp.x = (const void*)256; pp.y = (void*)256; pp.ldx = Cin; pp.ldy = Cout;
-        pp.N = N; pp.D = D; pp.H = H; pp.W = W; pp.K = Cin; pp.M = Cout;
-        if (msseg_k3direct_eligible(pp)) return 4;
-    }
     return cfg;
 }
 
@@ -917,7 +911,6 @@ static int k3_fwd_impl(const void* x, long long ldx, const void* wp, const float
         int cfg, cb;
         k3_plan(N, D, H, W, Cout, &cfg, &cb);   // the packed weight image must be the 32-wide one
         if (cb == 32 && msseg_k3pp_eligible(pp)) return msseg_k3pp_launch(pp, (hipStream_t)stream);
-        if (msseg_k3direct_eligible(pp)) return msseg_k3direct_launch(pp, cb, (hipStream_t)stream);
     }
     return dtype == MSSEG_F32 ? launch_k3<float>(p, (hipStream_t)stream) : launch_k3<bf16_t>(p, (hipStream_t)stream);
 }

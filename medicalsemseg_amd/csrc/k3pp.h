@@ -81,7 +81,3 @@ int msseg_deconv2_bwd_launch(const void* dy, long long lddy, const void* wp, voi
                              const float* fwd_stats, float slope, float eps, float* red, float* dgamma, float* dbeta,
                              int accumulate, float* dbias, int dbias_accumulate, void* scratch, size_t scratch_bytes,
                              hipStream_t stream);
-
-// ---- conv3d k3 on small grids: operands straight from the caches, one output block per wave (conv3d_k3_direct.hip) ----
-bool msseg_k3direct_eligible(const K3ppParams& p);
-int msseg_k3direct_launch(const K3ppParams& p, int cout_block, hipStream_t stream);
