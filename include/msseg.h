@@ -311,6 +311,13 @@ int msseg_gelu_bwd(const void* x, const void* dy, void* dx, long long n, int dty
 int msseg_dice_ce_partials(const void* logits, long long ld, int dtype, const void* labels, int label_dtype,
                            float* partial, float* hard, int N, long long S, int C, msseg_stream_t stream);
 /* loss[0] = mean_{n,c}(1 - (2I+snr)/(den+sdr)) + CE ; loss[1] = dice term, loss[2] = ce term. */
+/* Deterministic one-call form of the forward (N <= 8): per-block partial rows in `scratch` (the reduce scratch,
+ * msseg_reduce_scratch_bytes()), added in a fixed order by a one-block second step that also writes partial[N][C][4],
+ * hard[N][C][3] (nullable) and loss[3] = (dice + ce, dice, ce).  No zero-initialised outputs, no atomics: two runs on the
+ * same inputs give the same bits. */
+int msseg_dice_ce_fwd(const void* logits, long long ld, int dtype, const void* labels, int label_dtype, float* partial,
+                      float* hard, float* loss, int N, long long S, int C, float smooth_nr, float smooth_dr, void* scratch,
+                      size_t scratch_bytes, msseg_stream_t stream);
 int msseg_dice_ce_finalize(const float* partial, float* loss, int N, long long S, int C, float smooth_nr,
                            float smooth_dr, msseg_stream_t stream);
 /* dlogits = gscale[0] * dLoss/dlogits (same layout/dtype as logits). */

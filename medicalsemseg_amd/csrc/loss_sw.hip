@@ -46,7 +46,7 @@ template <typename T, int CMAX>
 __global__ __launch_bounds__(256) void dice_ce_partials_kernel(const T* __restrict__ logits, long long ld,
                                                                const void* __restrict__ labels, int label_dtype,
                                                                float* partial, float* hard, long long S, int C,
-                                                               long long vox_per_block) {
+                                                               long long vox_per_block, float* rows) {
     __shared__ float red[4][CMAX * 7];
     const long long n = blockIdx.y;
     const long long s0 = (long long)blockIdx.x * vox_per_block;
@@ -98,6 +98,10 @@ __global__ __launch_bounds__(256) void dice_ce_partials_kernel(const T* __restri
     for (int i = threadIdx.x; i < C * 7; i += 256) {
         const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
         const int c = i / 7, k = i % 7;
+        if (rows) {   // deterministic mode: one row per block, summed in a fixed order by dice_ce_rows_finalize_kernel
+            rows[((long long)n * gridDim.x + blockIdx.x) * (C * 7) + i] = v;
+            continue;
+        }
         if (k < 4) {
             if (partial) atomicAdd(&partial[(n * C + c) * 4 + k], v);
         } else if (hard) {
@@ -120,6 +124,53 @@ __global__ void dice_ce_finalize_kernel(const float* partial, float* loss, int N
     loss[0] = dice + ce;
     loss[1] = dice;
     loss[2] = ce;
+}
+
+// rows [N][nblk][C*7] -> partial[N][C][4], hard[N][C][3] (optional) and the loss triple, one block, fixed order
+__global__ __launch_bounds__(256) void dice_ce_rows_finalize_kernel(const float* rows, int nblk, float* partial, float* hard,
+                                                                    float* loss, int N, long long S, int C, float snr,
+                                                                    float sdr) {
+    __shared__ float tot[8 * 16 * 7];
+    const int L = C * 7;
+    // thread = (column o, row slot): 256 / L' slots per column add every slot-th row, then the slots are added in order
+    for (int n = 0; n < N; ++n) {
+        const float* base = rows + (long long)n * nblk * L;
+        const int cols = L < 256 ? L : 256, G = 256 / cols;
+        __shared__ float fin[256];
+        for (int c0 = 0; c0 < L; c0 += cols) {
+            const int col = threadIdx.x % cols, rg = threadIdx.x / cols, o = c0 + col;
+            float s = 0.f;
+            if (o < L && rg < G)
+                for (int b = rg; b < nblk; b += G) s += base[(long long)b * L + o];
+            __syncthreads();
+            fin[threadIdx.x] = s;
+            __syncthreads();
+            if (o < L && rg == 0) {
+                float t = 0.f;
+                for (int g = 0; g < G; ++g) t += fin[g * cols + col];
+                tot[n * L + o] = t;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * L; i += 256) {
+        const int n = i / L, o = i % L, c = o / 7, k = o % 7;
+        if (k < 4) partial[(n * C + c) * 4 + k] = tot[i];
+        else if (hard) hard[(n * C + c) * 3 + (k - 4)] = tot[i];
+    }
+    if (threadIdx.x == 0 && loss) {
+        float dice = 0.f, ce = 0.f;
+        for (int i = 0; i < N * C; ++i) {
+            const float I = tot[i * 7 + 0], p2 = tot[i * 7 + 1], t = tot[i * 7 + 2];
+            dice += 1.f - (2.f * I + snr) / (p2 + t + sdr);
+            ce += tot[i * 7 + 3];
+        }
+        dice /= (float)(N * C);
+        ce /= (float)((double)N * (double)S);
+        loss[0] = dice + ce;
+        loss[1] = dice;
+        loss[2] = ce;
+    }
 }
 
 template <typename T, int CMAX>
@@ -327,15 +378,28 @@ inline int grid_for(long long total, int per_thread = 4) {
 
 template <typename T, int CMAX>
 int launch_partials(const void* logits, long long ld, const void* labels, int label_dtype, float* partial, float* hard,
-                    int N, long long S, int C, hipStream_t st) {
+                    int N, long long S, int C, hipStream_t st, float* rows = nullptr, int* nblk_out = nullptr) {
     long long blocks = ceil_div_ll(S, 256LL * 8);
     const long long cap = (long long)msseg_num_cus() * 8 / N + 1;
     if (blocks > cap) blocks = cap;
     const long long vpb = ceil_div_ll(S, blocks);
     blocks = ceil_div_ll(S, vpb);
+    if (nblk_out) *nblk_out = (int)blocks;
     hipLaunchKernelGGL((dice_ce_partials_kernel<T, CMAX>), dim3((unsigned)blocks, N), dim3(256), 0, st, (const T*)logits,
-                       ld, labels, label_dtype, partial, hard, S, C, vpb);
+                       ld, labels, label_dtype, partial, hard, S, C, vpb, rows);
     MSSEG_CHECK_LAUNCH("dice_ce_partials");
+    return MSSEG_OK;
+}
+
+template <typename T, int CMAX>
+int launch_fwd(const void* logits, long long ld, const void* labels, int label_dtype, float* partial, float* hard,
+               float* loss, int N, long long S, int C, float snr, float sdr, float* rows, hipStream_t st) {
+    int nblk = 0;
+    const int rc = launch_partials<T, CMAX>(logits, ld, labels, label_dtype, partial, hard, N, S, C, st, rows, &nblk);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dice_ce_rows_finalize_kernel, dim3(1), dim3(256), 0, st, rows, nblk, partial, hard, loss, N, S, C,
+                       snr, sdr);
+    MSSEG_CHECK_LAUNCH("dice_ce_rows_finalize");
     return MSSEG_OK;
 }
 
@@ -376,6 +440,20 @@ int msseg_dice_ce_partials(const void* logits, long long ld, int dtype, const vo
         label_dtype < 0 || label_dtype > 3)
         MSSEG_FAIL(MSSEG_EINVAL, "dice_ce_partials: bad args (C=%d must be 1..16)", C);
     DISPATCH_TC(dtype, C, launch_partials, logits, ld, labels, label_dtype, partial, hard, N, S, C, (hipStream_t)stream);
+}
+
+int msseg_dice_ce_fwd(const void* logits, long long ld, int dtype, const void* labels, int label_dtype, float* partial,
+                      float* hard, float* loss, int N, long long S, int C, float smooth_nr, float smooth_dr, void* scratch,
+                      size_t scratch_bytes, msseg_stream_t stream) {
+    if (!logits || !labels || !partial || !loss || N < 1 || N > 8 || S < 1 || C < 1 || C > 16 || (ld != 0 && ld < C) ||
+        label_dtype < 0 || label_dtype > 3)
+        MSSEG_FAIL(MSSEG_EINVAL, "dice_ce_fwd: bad args (1 <= N <= 8, 1 <= C <= 16)");
+    const size_t need = MSSEG_SCRATCH_COUNTER_BYTES + (size_t)N * ((size_t)msseg_num_cus() * 8 / N + 2) * C * 7 * 4;
+    if (!scratch || ((uintptr_t)scratch & 255) || scratch_bytes < need)
+        MSSEG_FAIL(MSSEG_EWORKSPACE, "dice_ce_fwd: scratch of %zu bytes needed", need);
+    float* rows = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+    DISPATCH_TC(dtype, C, launch_fwd, logits, ld, labels, label_dtype, partial, hard, loss, N, S, C, smooth_nr, smooth_dr,
+                rows, (hipStream_t)stream);
 }
 
 int msseg_dice_ce_finalize(const float* partial, float* loss, int N, long long S, int C, float smooth_nr,

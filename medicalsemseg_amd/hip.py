@@ -87,6 +87,7 @@ SIGNATURES = {
     "msseg_channel_sum": ([_vp, _ll, _vp, _ll, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_add": ([_vp, _ll, _vp, _ll, _vp, _ll, _ll, _i, _i, _vp], _i),
     "msseg_dice_ce_partials": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _i, _ll, _i, _vp], _i),
+    "msseg_dice_ce_fwd": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _vp, _i, _ll, _i, _f, _f, _vp, _sz, _vp], _i),
     "msseg_dice_ce_finalize": ([_vp, _vp, _i, _ll, _i, _f, _f, _vp], _i),
     "msseg_dice_ce_bwd": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, _ll, _i, _f, _f, _vp], _i),
     "msseg_adamw_step": ([_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp], _i),
@@ -710,6 +711,21 @@ def dice_ce_partials(logits, labels, n_cls, channels_last_ld=0, want_hard=False)
     _ck(lib().msseg_dice_ce_partials(_p(logits), channels_last_ld, dt(logits), _p(labels), _LAB[labels.dtype],
                                      _p(partial), _p(hard), N, S, n_cls, _stream()), "dice_ce_partials")
     return partial, hard
+
+
+def dice_ce_fwd(logits, labels, n_cls, smooth_nr, smooth_dr, channels_last_ld=0, want_hard=True):
+    """deterministic fused forward: returns (partial [N,C,4], hard [N,C,3] or None, loss3 = (total, dice, ce))"""
+    _need_gpu(logits, labels)
+    N = logits.shape[0]
+    S = labels.numel() // N
+    partial = torch.empty(N, n_cls, 4, dtype=torch.float32, device=logits.device)
+    hard = torch.empty(N, n_cls, 3, dtype=torch.float32, device=logits.device) if want_hard else None
+    loss = torch.empty(3, dtype=torch.float32, device=logits.device)
+    sc = scratch(logits.device)
+    _ck(lib().msseg_dice_ce_fwd(_p(logits), channels_last_ld, dt(logits), _p(labels), _LAB[labels.dtype], _p(partial),
+                                _p(hard), _p(loss), N, S, n_cls, smooth_nr, smooth_dr, _p(sc), sc.numel(), _stream()),
+        "dice_ce_fwd")
+    return partial, hard, loss
 
 
 def dice_ce_finalize(partial, S, smooth_nr, smooth_dr):

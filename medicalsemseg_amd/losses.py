@@ -64,8 +64,11 @@ class _DiceCEFn(torch.autograd.Function):
         S = logits.numel() // (N * C)
         if labels.numel() != N * S:
             raise ValueError(f"labels {tuple(labels.shape)} do not match logits {tuple(logits.shape)}")
-        partial, hard = hip.dice_ce_partials(logits, labels, C, ld, want_hard=True)
-        loss3 = hip.dice_ce_finalize(partial, S, smooth_nr, smooth_dr)
+        if N <= 8:   # deterministic two-step reduction (no atomics, no zero-filled outputs)
+            partial, hard, loss3 = hip.dice_ce_fwd(logits, labels, C, smooth_nr, smooth_dr, ld, want_hard=True)
+        else:
+            partial, hard = hip.dice_ce_partials(logits, labels, C, ld, want_hard=True)
+            loss3 = hip.dice_ce_finalize(partial, S, smooth_nr, smooth_dr)
         ctx.save_for_backward(logits, labels, partial)
         ctx.sm = (smooth_nr, smooth_dr)
         ctx.ld = ld
@@ -73,7 +76,7 @@ class _DiceCEFn(torch.autograd.Function):
             holder["hard"] = hard          # [N, C, 3] = (|P&T|, |P|, |T|) for the metric
             holder["parts"] = loss3        # (total, dice, ce)
             holder["of"] = (logits.data_ptr(), tuple(logits.shape))   # which logits these by-products belong to
-        return loss3[0].clone()
+        return loss3[0]
 
     @staticmethod
     def backward(ctx, g):
