@@ -226,3 +226,16 @@ def test_eval_model_and_test_model_vs_oracle(tmp_path):
     voted = majority_vote([maps[0], maps[0], maps[1]], 3).cpu().numpy()
     from oracle.postproc import majority_vote as mv_ref
     assert np.array_equal(voted, mv_ref(np.stack([maps[0], maps[0], maps[1]]), 3))
+
+
+def test_overlapped_gradient_exchange_equals_plain_exchange_two_ranks():
+    """2 gloo ranks on this GPU: three data-parallel optimiser steps with the all-reduce of the finished gradient suffix
+    running under the backward tail (eager, and as graph A1 | collective | graph A2 | collective | graph B) leave the
+    same bits as one all-reduce after the whole backward (tools/dp_overlap_check.py)"""
+    env = dict(os.environ, MSSEG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29650 + os.getpid() % 200),
+                        os.path.join(ROOT, "tools", "dp_overlap_check.py")], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "DP_OVERLAP_OK" in r.stdout

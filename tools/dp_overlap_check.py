@@ -1,0 +1,118 @@
+"""Run under torch.distributed.run with 2 ranks on ONE GPU over gloo (tests/test_gpu_engine.py).
+
+Data-parallel step of the UNet with the two-phase backward: the flat gradient suffix the backward head finished is
+all-reduced asynchronously while the backward tail runs (parallel.GradSync.start / finish).  Three optimiser steps are
+run in four arrangements and must leave bit-identical parameters on every rank:
+  eager   + overlapped    eager   + one all-reduce after the whole backward
+  graphs (A1 | async all-reduce | A2 tail | all-reduce | B optimiser) + overlapped     graphs + not overlapped
+Ordering contract exercised here: the collective is enqueued on the process group's stream AFTER an event recorded on the
+current stream (so after the head graph), the tail graph writes only flat_grad[:split], and finish() waits for both
+collectives before the optimiser graph reads the buffer."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from medicalsemseg_amd import layers, parallel  # noqa: E402
+from medicalsemseg_amd.losses import DiceCELoss  # noqa: E402
+from medicalsemseg_amd.models.unet import UNET_FEATURES, UNet  # noqa: E402
+from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay  # noqa: E402
+
+
+def run(overlap: bool, graphs: bool, rank: int, dev):
+    if overlap:
+        os.environ.pop("MSSEG_NO_GRAD_OVERLAP", None)
+    else:
+        os.environ["MSSEG_NO_GRAD_OVERLAP"] = "1"
+    torch.manual_seed(0)
+    net = UNet(1, 2, UNET_FEATURES["UNetSmall"], compute_dtype=torch.bfloat16).to(dev)
+    opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=1e-3, betas=(0.9, 0.95), eps=1e-6)
+    torch.distributed.broadcast(opt.flat_param, src=0)
+    layers.bump_weights_epoch()
+    crit = DiceCELoss()
+    g = torch.Generator().manual_seed(100 + rank)              # per-rank data
+    x = torch.randn(2, 1, 32, 32, 32, generator=g).to(dev)
+    y = torch.randint(0, 2, (2, 1, 32, 32, 32), generator=g).float().to(dev)
+    gsync = parallel.GradSync(opt, net)
+    assert gsync.overlapped == overlap
+    two_phase = bool(getattr(net, "_defer_tail", False))
+
+    def part_a():
+        loss = crit(net((x, None, None)), y)
+        loss.backward()
+        return loss
+
+    def part_b():
+        opt.step()
+        opt.zero_grad()
+
+    def eager_step():
+        part_a()
+        if two_phase:
+            gsync.start()
+            net.backward_tail()
+        gsync.finish()
+        part_b()
+
+    if not graphs:
+        for _ in range(3):
+            eager_step()
+    else:
+        eager_step()                                           # warm-up (step 1)
+        torch.cuda.synchronize()
+        layers.PACK_REGISTRY.prepare()
+        layers.bump_weights_epoch()
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            part_a()
+        gt = None
+        if two_phase:
+            gsync.start()
+            gt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gt, pool=ga.pool()):
+                net.backward_tail()
+        gsync.finish()
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb):
+            part_b()                                           # (step 2 happened during capture)
+        layers.bump_weights_epoch()
+        ga.replay()                                            # step 3
+        if gt is not None:
+            gsync.start()
+            gt.replay()
+        gsync.finish()
+        gb.replay()
+    torch.cuda.synchronize()
+    net.defer_backward_tail(False)
+    return opt.flat_param.clone()
+
+
+def main():
+    parallel.init_from_env()
+    rank = parallel.rank()
+    assert parallel.world_size() == 2
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    res = {}
+    for overlap in (True, False):
+        for graphs in (False, True):
+            res[(overlap, graphs)] = run(overlap, graphs, rank, dev)
+    ref = res[(False, False)]
+    for k, v in res.items():
+        assert torch.equal(v, ref), f"rank {rank}: arrangement overlap={k[0]} graphs={k[1]} differs: " \
+                                    f"{float((v - ref).abs().max())}"
+    # both ranks hold the same parameters
+    other = ref.clone()
+    torch.distributed.broadcast(other, src=0)
+    assert torch.equal(other, ref)
+    torch.distributed.barrier()
+    if rank == 0:
+        print("DP_OVERLAP_OK", flush=True)
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
