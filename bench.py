@@ -385,6 +385,7 @@ def main():
                 with torch.cuda.graph(graph_b):
                     part_b()
                 layers.bump_weights_epoch()
+                opt._gscale.fill_(1.0)    # finish() above folded 1/world into the scale; the captured step did not run
             replay()
             sync()
         except Exception as e:  # noqa: BLE001

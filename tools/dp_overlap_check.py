@@ -77,14 +77,16 @@ def run(overlap: bool, graphs: bool, rank: int, dev):
         gsync.finish()
         gb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gb):
-            part_b()                                           # (step 2 happened during capture)
+            part_b()
         layers.bump_weights_epoch()
-        ga.replay()                                            # step 3
-        if gt is not None:
-            gsync.start()
-            gt.replay()
-        gsync.finish()
-        gb.replay()
+        opt._gscale.fill_(1.0)        # the collectives issued between the captures ran for real (on zero gradients)
+        for _ in range(2):                                     # steps 2 and 3
+            ga.replay()
+            if gt is not None:
+                gsync.start()
+                gt.replay()
+            gsync.finish()
+            gb.replay()
     torch.cuda.synchronize()
     net.defer_backward_tail(False)
     return opt.flat_param.clone()
