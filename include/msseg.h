@@ -281,6 +281,17 @@ int msseg_window_attention_bwd(const void* qkv, const float* qkv_bias, const flo
  * for one).  With it the bias-table gradient (swin_nnformer.py:147-155 in reverse) is computed without atomics: dS tiles
  * in bf16 -> sum over windows -> gather per table entry, deterministic.  workspace == NULL behaves as the call above. */
 size_t msseg_window_attention_bwd_workspace_bytes(int B, int S, int H, int W, int C, int heads, int ws, int shift, int dtype);
+/* Forms with a separate BIAS window: the table has (2*bias_ws-1)^3 rows and token i of a window takes the relative
+ * position of index position decode_{bias_ws}(i) -- MONAI SwinUNETR builds table and index for window 7 and slices the
+ * index [:n, :n] when the window is clamped to a smaller grid (swin_unetr_official.py:375-385, 477-480).  bias_ws == ws is
+ * the plain case (bf16 then runs on the MFMA kernels); bias_ws > ws runs on the exact-fp32-math kernels. */
+int msseg_window_attention_fwd2(const void* qkv, const float* qkv_bias, const float* table, void* out, float* lse, int B,
+                                int S, int H, int W, int C, int heads, int ws, int shift, int bias_ws, int dtype,
+                                msseg_stream_t stream);
+int msseg_window_attention_bwd2(const void* qkv, const float* qkv_bias, const float* table, const void* out,
+                                const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
+                                int C, int heads, int ws, int shift, int bias_ws, int dtype, void* workspace,
+                                size_t workspace_bytes, msseg_stream_t stream);
 int msseg_window_attention_bwd_ws(const void* qkv, const float* qkv_bias, const float* table, const void* out,
                                   const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
                                   int C, int heads, int ws, int shift, int dtype, void* workspace, size_t workspace_bytes,

@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const AttnParams p) {
     int* regS = tok + p.N;               // [N]
     int* codeS = regS + p.N;             // [N]
     const int nW = p.nWs * p.nWh * p.nWw;
-    const int m = 2 * p.ws - 1;
-    const int off = ((p.ws - 1) * m + (p.ws - 1)) * m + (p.ws - 1);
+    const int m = 2 * p.bws - 1;
+    const int off = ((p.bws - 1) * m + (p.bws - 1)) * m + (p.bws - 1);
     for (int wb = blockIdx.x; wb < p.nwin_total; wb += gridDim.x) {
         const int w = wb % nW, b = wb / nW;
         const int wx = w % p.nWw, wy = (w / p.nWw) % p.nWh, wz = w / (p.nWw * p.nWh);
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(const AttnParams p) {
     int* codeS = regS + p.N;
     float* dtabS = (float*)(codeS + p.N);  // [M3] or [heads][M3]
     const int nW = p.nWs * p.nWh * p.nWw;
-    const int m = 2 * p.ws - 1;
-    const int off = ((p.ws - 1) * m + (p.ws - 1)) * m + (p.ws - 1);
+    const int m = 2 * p.bws - 1;
+    const int off = ((p.bws - 1) * m + (p.bws - 1)) * m + (p.bws - 1);
     const long long vol = (long long)p.S * p.H * p.W;
     const int ndt = p.dtable ? (p.dtab_all_heads ? p.heads * p.M3 : p.M3) : 0;
     for (int i = threadIdx.x; i < ndt; i += 256) dtabS[i] = 0.f;
@@ -454,14 +454,17 @@ inline int grid_for(long long total, int per_thread = 4) {
     return (int)b;
 }
 
-int fill_attn(AttnParams& p, int B, int S, int H, int W, int C, int heads, int ws, int shift) {
+int fill_attn(AttnParams& p, int B, int S, int H, int W, int C, int heads, int ws, int shift, int bias_ws = 0) {
     if (B < 1 || S < 1 || H < 1 || W < 1 || heads < 1 || C % heads || ws < 1 || shift < 0 || shift >= ws)
         MSSEG_FAIL(MSSEG_EINVAL, "window_attention: bad shape");
+    if (bias_ws == 0) bias_ws = ws;
+    if (bias_ws < ws) MSSEG_FAIL(MSSEG_EINVAL, "window_attention: bias window %d smaller than the window %d", bias_ws, ws);
+    p.bws = bias_ws;
     p.B = B; p.S = S; p.H = H; p.W = W; p.C = C; p.heads = heads; p.hd = C / heads; p.ws = ws; p.shift = shift;
     p.nWs = ceil_div(S, ws); p.nWh = ceil_div(H, ws); p.nWw = ceil_div(W, ws);
     p.Sp = p.nWs * ws; p.Hp = p.nWh * ws; p.Wp = p.nWw * ws;
     p.N = ws * ws * ws;
-    p.M3 = (2 * ws - 1) * (2 * ws - 1) * (2 * ws - 1);
+    p.M3 = (2 * bias_ws - 1) * (2 * bias_ws - 1) * (2 * bias_ws - 1);
     p.nwin_total = p.nWs * p.nWh * p.nWw * B;
     p.scale = 1.0f / sqrtf((float)p.hd);
     p.use_mask = shift > 0;
@@ -496,13 +499,20 @@ static int attn_set_lds(const void* kern, size_t smem) {
 int msseg_window_attention_fwd(const void* qkv, const float* qkv_bias, const float* table, void* out, float* lse, int B,
                                int S, int H, int W, int C, int heads, int ws, int shift, int dtype,
                                msseg_stream_t stream) {
+    return msseg_window_attention_fwd2(qkv, qkv_bias, table, out, lse, B, S, H, W, C, heads, ws, shift, ws, dtype, stream);
+}
+
+int msseg_window_attention_fwd2(const void* qkv, const float* qkv_bias, const float* table, void* out, float* lse, int B,
+                                int S, int H, int W, int C, int heads, int ws, int shift, int bias_ws, int dtype,
+                                msseg_stream_t stream) {
     if (!qkv || !table || !out || !lse) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd: null pointer");
     AttnParams p{};
-    if (int rc = fill_attn(p, B, S, H, W, C, heads, ws, shift)) return rc;
+    if (int rc = fill_attn(p, B, S, H, W, C, heads, ws, shift, bias_ws)) return rc;
     p.qkv = qkv; p.qkv_bias = qkv_bias; p.table = table; p.out = out; p.lse = lse;
     const size_t smem = (size_t)p.N * p.hd * 2 * 4 + (size_t)p.M3 * 4 + (size_t)p.N * 3 * 4;
     if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd: window too large for LDS");
-    if (dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 224 && (C % 8) == 0 && !getenv("MSSEG_ATTN_NO_MFMA")) {
+    if (dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 224 && p.M3 <= 2047 && p.bws == p.ws && (C % 8) == 0 &&
+        !getenv("MSSEG_ATTN_NO_MFMA")) {
         // bf16: QK^T and PV on the matrix cores (attention_mfma.hip)
         return msseg_window_attention_fwd_mfma(p, (hipStream_t)stream);
     }
@@ -514,7 +524,7 @@ int msseg_window_attention_fwd(const void* qkv, const float* qkv_bias, const flo
 }
 
 static bool attn_bwd_on_mfma(const AttnParams& p, int C, int dtype) {
-    return dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 224 && p.M3 <= 2047 && (C % 8) == 0 &&
+    return dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 224 && p.M3 <= 2047 && p.bws == p.ws && (C % 8) == 0 &&
            !getenv("MSSEG_ATTN_NO_MFMA") && !getenv("MSSEG_ATTN_BWD_NO_MFMA");
 }
 
@@ -529,9 +539,17 @@ int msseg_window_attention_bwd_ws(const void* qkv, const float* qkv_bias, const 
                                   const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
                                   int C, int heads, int ws, int shift, int dtype, void* workspace, size_t workspace_bytes,
                                   msseg_stream_t stream) {
+    return msseg_window_attention_bwd2(qkv, qkv_bias, table, out, lse, dout, dqkv, dtable, B, S, H, W, C, heads, ws, shift, ws,
+                                       dtype, workspace, workspace_bytes, stream);
+}
+
+int msseg_window_attention_bwd2(const void* qkv, const float* qkv_bias, const float* table, const void* out,
+                                const float* lse, const void* dout, void* dqkv, float* dtable, int B, int S, int H, int W,
+                                int C, int heads, int ws, int shift, int bias_ws, int dtype, void* workspace,
+                                size_t workspace_bytes, msseg_stream_t stream) {
     if (!qkv || !table || !out || !lse || !dout || !dqkv) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd: null pointer");
     AttnParams p{};
-    if (int rc = fill_attn(p, B, S, H, W, C, heads, ws, shift)) return rc;
+    if (int rc = fill_attn(p, B, S, H, W, C, heads, ws, shift, bias_ws)) return rc;
     p.qkv = qkv; p.qkv_bias = qkv_bias; p.table = table; p.out = (void*)out; p.lse = (float*)lse; p.dout = dout;
     p.dqkv = dqkv; p.dtable = dtable;
     if (attn_bwd_on_mfma(p, C, dtype)) {

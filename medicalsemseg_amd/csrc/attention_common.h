@@ -20,6 +20,9 @@ struct AttnParams {
     float* ds_psum;       // fp32 [ds_groups][heads][NKT*NKT][64][16]
     int ds_groups;
     int B, S, H, W, C, heads, hd, ws, shift;
+    int bws;              // window edge the bias table / index were BUILT for (>= ws; MONAI SwinUNETR slices the 7^3 index
+                          // [:n, :n] when the window is clamped to a smaller grid: token i then takes the bias of position
+                          // decode_bws(i), swin_unetr_official.py:477-480)
     int Sp, Hp, Wp, nWs, nWh, nWw, N, M3, nwin_total;
     float scale;
     int use_mask;
@@ -32,7 +35,11 @@ MSSEG_DEVFN int region_id(int z, int Lp, int ws, int shift) { return z < Lp - ws
 MSSEG_DEVFN int window_token(const AttnParams& p, int wz, int wy, int wx, int pos, int& reg, int& code) {
     const int ws = p.ws;
     const int pz = pos / (ws * ws), py = (pos / ws) % ws, px = pos % ws;
-    code = (pz * (2 * ws - 1) + py) * (2 * ws - 1) + px;  // rel_index(i, j) = code_i - code_j + off
+    {   // rel_index(i, j) = code_i - code_j + off, positions decoded on the grid the index was built for
+        const int b = p.bws, m = 2 * b - 1;
+        const int bz = pos / (b * b), by = (pos / b) % b, bx = pos % b;
+        code = (bz * m + by) * m + bx;
+    }
     const int sz = wz * ws + pz, sy = wy * ws + py, sx = wx * ws + px;  // coordinates in the shifted, padded grid
     reg = region_id(sz, p.Sp, ws, p.shift) * 9 + region_id(sy, p.Hp, ws, p.shift) * 3 + region_id(sx, p.Wp, ws, p.shift);
     int z = sz + p.shift, y = sy + p.shift, x = sx + p.shift;      // shifted[i] = x[(i + shift) mod Lp]

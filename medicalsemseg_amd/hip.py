@@ -50,6 +50,9 @@ SIGNATURES = {
     "msseg_window_attention_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_window_attention_bwd_ws": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
                                        _sz, _vp], _i),
+    "msseg_window_attention_fwd2": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_window_attention_bwd2": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
+                                     _sz, _vp], _i),
     "msseg_window_attention_bwd_workspace_bytes": ([_i, _i, _i, _i, _i, _i, _i, _i, _i], _sz),
     "msseg_layernorm_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _ll, _i, _f, _i, _vp], _i),
     "msseg_layernorm_bwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _vp], _i),
@@ -873,30 +876,32 @@ def zero_stuff2(dy, out):
     return out
 
 
-def window_attention_fwd(qkv, qkv_bias, table, out, heads, ws, shift):
-    """qkv [B,S,H,W,3C] contiguous -> out [B,S,H,W,C]; returns lse for the backward."""
+def window_attention_fwd(qkv, qkv_bias, table, out, heads, ws, shift, bias_ws=None):
+    """qkv [B,S,H,W,3C] contiguous -> out [B,S,H,W,C]; returns lse for the backward.  bias_ws: window edge the bias table
+    was built for (MONAI SwinUNETR: 7 even where the window is clamped to a smaller grid)."""
     _need_gpu(qkv, table, out)
     assert qkv.is_contiguous() and out.is_contiguous()
     B, S, H, W, C3 = qkv.shape
     Cc = C3 // 3
     nW = -(-S // ws) * -(-H // ws) * -(-W // ws)
     lse = torch.empty(B * nW, heads, ws ** 3, dtype=torch.float32, device=qkv.device)
-    _ck(lib().msseg_window_attention_fwd(_p(qkv), _p(qkv_bias), _p(table), _p(out), _p(lse), B, S, H, W, Cc, heads, ws,
-                                         shift, dt(qkv), _stream()), "window_attention_fwd")
+    _ck(lib().msseg_window_attention_fwd2(_p(qkv), _p(qkv_bias), _p(table), _p(out), _p(lse), B, S, H, W, Cc, heads, ws,
+                                          shift, bias_ws or ws, dt(qkv), _stream()), "window_attention_fwd")
     return lse
 
 
-def window_attention_bwd(qkv, qkv_bias, table, out, lse, dout, dqkv, dtable, heads, ws, shift):
+def window_attention_bwd(qkv, qkv_bias, table, out, lse, dout, dqkv, dtable, heads, ws, shift, bias_ws=None):
     _need_gpu(qkv, table, out, lse, dout, dqkv)
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
     B, S, H, W, C3 = qkv.shape
     wsb = 0
-    if dtable is not None:
+    bws = bias_ws or ws
+    if dtable is not None and bws == ws:
         wsb = int(lib().msseg_window_attention_bwd_workspace_bytes(B, S, H, W, C3 // 3, heads, ws, shift, dt(qkv)))
     work = torch.empty(wsb, dtype=torch.uint8, device=qkv.device) if wsb else None
-    _ck(lib().msseg_window_attention_bwd_ws(_p(qkv), _p(qkv_bias), _p(table), _p(out), _p(lse), _p(dout), _p(dqkv),
-                                            _p(dtable), B, S, H, W, C3 // 3, heads, ws, shift, dt(qkv), _p(work), wsb,
-                                            _stream()), "window_attention_bwd")
+    _ck(lib().msseg_window_attention_bwd2(_p(qkv), _p(qkv_bias), _p(table), _p(out), _p(lse), _p(dout), _p(dqkv),
+                                          _p(dtable), B, S, H, W, C3 // 3, heads, ws, shift, bws, dt(qkv), _p(work), wsb,
+                                          _stream()), "window_attention_bwd")
     return dqkv
 
 

@@ -5,6 +5,9 @@ for the models on the hot path.
   UNet).
 * ``cfg.model == 'nnFormerUNETR'`` -- ``SwinTransformerNNFormer`` encoder + ``SwinUNETRCustom`` decoder, the branch
   at ``model_builder.py:15-66``.
+* ``cfg.model == 'SwinUNETR'`` -- the vendored MONAI variant of ``models/segmentors/swin_unetr_official.py`` (window 7,
+  ``feature_size = cfg.hidden_dim``), the literal "Swin-UNETR 48-feat" of BASELINE.json configs[3] (the reference keeps
+  the class but wires no ``build_model`` branch to it).
 Every returned module obeys the engine contract ``model((vol, rel_crop_loc, affine_xyz)) -> logits`` and keeps the
 reference's / MONAI's state-dict key layout.  ``cfg.compute_dtype``: 'bf16' (default) or 'f32'.
 """
@@ -47,7 +50,11 @@ def build_model(cfg):
         return SwinUNETRCustom(encoder, in_channels=cfg.in_chans, out_channels=cfg.output_dim,
                                img_size=_t3(cfg.vol_size), hidden_size=cfg.hidden_dim, patch_size=_t3(cfg.patch_size),
                                compute_dtype=_dtype(cfg))
+    if name == "SwinUNETR":
+        from .swin_unetr_official import SwinUNETR
+        return SwinUNETR(_t3(cfg.vol_size), cfg.in_chans, cfg.output_dim, depths=tuple(cfg.depths),
+                         num_heads=tuple(cfg.num_heads), feature_size=cfg.hidden_dim, compute_dtype=_dtype(cfg))
     if name in OUT_OF_SCOPE:
         raise NotImplementedError(f"model '{name}' is a research variant outside this build's hot-path scope "
-                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR']")
+                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR', 'SwinUNETR']")
     raise ValueError(f"unknown cfg.model '{name}'")

@@ -120,22 +120,22 @@ class WindowAttnFn(torch.autograd.Function):
     """shifted-window attention core on a token volume: qkv [B,S,H,W,3C] -> [B,S,H,W,C]"""
 
     @staticmethod
-    def forward(ctx, qkv, qkv_bias, table, heads, ws, shift):
+    def forward(ctx, qkv, qkv_bias, table, heads, ws, shift, bias_ws=None):
         qkv = _c(qkv)
         B, S, H, W, C3 = qkv.shape
         out = torch.empty(B, S, H, W, C3 // 3, dtype=qkv.dtype, device=qkv.device)
         qb = qkv_bias.detach() if qkv_bias is not None else None
         tab = table.detach().contiguous()
-        lse = hip.window_attention_fwd(qkv, qb, tab, out, heads, ws, shift)
+        lse = hip.window_attention_fwd(qkv, qb, tab, out, heads, ws, shift, bias_ws)
         ctx.save_for_backward(qkv, qb, tab, out, lse)
-        ctx.cfg = (heads, ws, shift)
+        ctx.cfg = (heads, ws, shift, bias_ws)
         ctx.table = table
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, qb, tab, out, lse = ctx.saved_tensors
-        heads, ws, shift = ctx.cfg
+        heads, ws, shift, bias_ws = ctx.cfg
         dqkv = torch.empty_like(qkv)
         dtable = None
         if ctx.needs_input_grad[2]:
@@ -146,9 +146,9 @@ class WindowAttnFn(torch.autograd.Function):
                     dtable.zero_()
             else:
                 dtable = torch.zeros_like(tab)
-        hip.window_attention_bwd(qkv, qb, tab, out, lse, _c(dout), dqkv, dtable, heads, ws, shift)
+        hip.window_attention_bwd(qkv, qb, tab, out, lse, _c(dout), dqkv, dtable, heads, ws, shift, bias_ws)
         # gradient w.r.t. qkv_bias through PADDED tokens (only when the grid is not a window multiple) is dropped
-        return dqkv, None, (None if ctx.table.is_contiguous() else dtable), None, None, None
+        return dqkv, None, (None if ctx.table.is_contiguous() else dtable), None, None, None, None
 
 
 class Conv3Fn(torch.autograd.Function):

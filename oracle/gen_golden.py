@@ -254,6 +254,79 @@ def gen_layers():
     _save("layers_ref.npz", dp_x=x, dp_y=y, dp_eval=dp_eval, tn=t, tn2=t2)
 
 
+def gen_swin_official():
+    """The reference's own models/segmentors/swin_unetr_official.py (vendored MONAI SwinUNETR: window 7, Linear patch merging
+    with the duplicated sub-grids, index slicing when the window is clamped, un-affine proj_out) with the MONAI block names
+    it imports bound to oracle/blocks.py's restatements.  Encoder features + gradients and the whole network's logits."""
+    import importlib
+    from oracle import blocks as ob
+
+    class _Conv:
+        CONV = "conv"
+
+        def __getitem__(self, key):
+            assert key[0] == "conv" and key[1] == 3
+            return torch.nn.Conv3d
+
+    def basic(spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, res_block=True):
+        assert spatial_dims == 3 and res_block and norm_name == "instance"
+        return ob.UnetrBasicBlock(in_channels, out_channels, kernel_size, stride)
+
+    def up(spatial_dims, in_channels, out_channels, kernel_size, upsample_kernel_size, norm_name, res_block=True):
+        assert spatial_dims == 3 and res_block and norm_name == "instance"
+        return ob.UnetrUpBlock(in_channels, out_channels, kernel_size, upsample_kernel_size)
+
+    def outb(spatial_dims, in_channels, out_channels):
+        return ob.UnetOutBlock(in_channels, out_channels)
+
+    def optional_import(module, name="", **kw):
+        try:
+            m = importlib.import_module(module)
+            return (getattr(m, name) if name else m), True
+        except ImportError:
+            return None, False
+
+    def look_up_option(opt, supported, default=None):
+        if opt in supported:
+            return opt
+        raise ValueError(opt)
+
+    sys.modules["monai.networks.blocks"].UnetOutBlock = outb
+    sys.modules["monai.networks.blocks"].UnetrBasicBlock = basic
+    sys.modules["monai.networks.blocks"].UnetrUpBlock = up
+    sys.modules["monai.networks.layers"].Conv = _Conv()
+    sys.modules["monai.networks.layers"].get_act_layer = lambda act: torch.nn.GELU()
+    sys.modules["monai.utils"].optional_import = optional_import
+    sys.modules["monai.utils"].look_up_option = look_up_option
+    for m in ("models.blocks.mlp", "models.blocks.patch_embeddings", "models.segmentors.swin_unetr_official"):
+        sys.modules.pop(m, None)
+    R = importlib.import_module("models.segmentors.swin_unetr_official")
+    # (a) encoder at 28^3 (token grid 14 -> 7 -> 4 -> 2 -> 1: padded windows, clamped windows with sliced index)
+    vit = R.SwinTransformer(in_chans=1, embed_dim=24, window_size=(7, 7, 7), patch_size=(2, 2, 2), depths=(2, 2, 2, 2),
+                            num_heads=(3, 6, 12, 24), spatial_dims=3)
+    det_fill_(vit, "swo_vit.")
+    x = det_tensor("swo_x28", (1, 1, 28, 28, 28)).requires_grad_(True)
+    outs = vit(x, normalize=True)
+    loss = sum((o * det_tensor(f"swo_r{i}", o.shape)).sum() for i, o in enumerate(outs))
+    loss.backward()
+    blk = vit.layers1[0].blocks[1]
+    _save("swin_official_encoder.npz", dx=x.grad, d_qkv_w=blk.attn.qkv.weight.grad, d_qkv_b=blk.attn.qkv.bias.grad,
+          d_table=blk.attn.relative_position_bias_table.grad, d_merge_w=vit.layers1[0].downsample.reduction.weight.grad,
+          d_table_l2=vit.layers2[0].blocks[1].attn.relative_position_bias_table.grad,
+          **{f"out{i}": o for i, o in enumerate(outs)})
+    # (b) the whole network at 64^3 (the deepest feature map must keep more than one voxel for InstanceNorm), feature size 12
+    net = R.SwinUNETR(img_size=(64, 64, 64), in_channels=1, out_channels=3, feature_size=12)
+    det_fill_(net, "swo_net.")
+    x2 = det_tensor("swo_x64", (1, 1, 64, 64, 64))
+    y = net(x2)
+    (y * det_tensor("swo_ry", y.shape)).sum().backward()
+    _save("swin_official_net.npz", logits_s2=y[:, :, ::2, ::2, ::2], logits_sum=y.double().sum(), logits_abs=y.double().abs().sum(),
+          d_out_w=net.out.conv.conv.weight.grad,
+          d_enc1_w=net.encoder1.layer.conv1.conv.weight.grad,
+          d_patch_w=net.swinViT.patch_embed.proj.weight.grad,
+          d_l4_fc=net.swinViT.layers4[0].blocks[0].mlp.linear1.weight.grad)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("needs /root/reference (build container only)")
@@ -268,6 +341,7 @@ def main():
     gen_unetr_conv_blocks()
     gen_sliding_window_loop()
     gen_layers()
+    gen_swin_official()
 
 
 if __name__ == "__main__":

@@ -174,3 +174,80 @@ def test_swin_unetr_vs_oracle(dtype):
         den += float((gr ** 2).sum())
     tot = (num / den) ** 0.5
     assert tot < (2e-3 if dtype == torch.float32 else 0.15), f"whole-net grad rel L2 err {tot:.3e}"
+
+
+def test_swin_official_encoder_vs_reference_golden(golden_dir):
+    """product SwinViT (MONAI / official variant: padded 7-windows, clamped windows with the sliced 7^3 index,
+    duplicated-sub-grid Linear patch merging, un-affine proj_out) against vectors of the REFERENCE's own
+    swin_unetr_official.py; token grid 14 -> 7 -> 4 -> 2 -> 1"""
+    from medicalsemseg_amd import hip
+    from medicalsemseg_amd.models.swin_unetr_official import _SwinViT
+    g = _load(golden_dir, "swin_official_encoder.npz")
+    vit = _SwinViT(1, 24, 7, (2, 2, 2, 2), (3, 6, 12, 24))
+    det_fill_(vit, "swo_vit.")
+    vit = vit.to(DEV)
+    x = det_tensor("swo_x28", (1, 1, 28, 28, 28)).to(DEV)
+    x_cl = torch.empty(1, 28, 28, 28, 1, device=DEV)
+    hip.to_channels_last(x, x_cl)
+    outs = vit(x_cl, True)
+    loss = 0
+    for i, o in enumerate(outs):
+        got = o.permute(0, 4, 1, 2, 3)
+        assert _rel(got, g[f"out{i}"]) < 1e-3, f"feature {i}"
+        loss = loss + (got * det_tensor(f"swo_r{i}", g[f"out{i}"].shape).to(DEV)).sum()
+    loss.backward()
+    blk = vit.layers1[0].blocks[1]
+    assert _rel(blk.attn.qkv.weight.grad, g["d_qkv_w"]) < 5e-3
+    assert _rel(blk.attn.qkv.bias.grad, g["d_qkv_b"]) < 5e-3          # incl. the padded tokens' share
+    assert _rel(blk.attn.relative_position_bias_table.grad, g["d_table"]) < 5e-3
+    assert _rel(vit.layers1[0].downsample.reduction.weight.grad, g["d_merge_w"]) < 5e-3
+    assert _rel(vit.layers2[0].blocks[1].attn.relative_position_bias_table.grad, g["d_table_l2"]) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swin_official_net_vs_reference_golden_and_oracle(golden_dir, dtype):
+    """whole official Swin-UNETR (feature 12, 64^3): logits / gradients against the reference-file golden (fp32) and
+    against the oracle restatement on random labels with DiceCE (both dtypes)"""
+    from medicalsemseg_amd.losses import DiceCELoss
+    from medicalsemseg_amd.models.swin_unetr_official import SwinUNETR
+    from oracle import swin_official as O
+    from oracle.losses import dice_ce_loss
+    gn = _load(golden_dir, "swin_official_net.npz")
+    ref = O.SwinUNETR((64, 64, 64), 1, 3, feature_size=12)
+    det_fill_(ref, "swo_net.")
+    net = SwinUNETR((64, 64, 64), 1, 3, feature_size=12, compute_dtype=dtype)
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(DEV)
+    x = det_tensor("swo_x64", (1, 1, 64, 64, 64))
+    out = net(x.to(DEV))                       # bare volume, as MONAI's inferer calls it
+    if dtype == torch.float32:
+        assert _rel(out[:, :, ::2, ::2, ::2], gn["logits_s2"]) < 2e-4
+        (out * det_tensor("swo_ry", tuple(out.shape)).to(DEV)).sum().backward()
+        assert _rel(net.out.conv.conv.weight.grad, gn["d_out_w"]) < 2e-3
+        assert _rel(net.encoder1.layer.conv1.conv.weight.grad, gn["d_enc1_w"]) < 2e-3
+        assert _rel(net.swinViT.patch_embed.proj.weight.grad, gn["d_patch_w"]) < 5e-3
+        assert _rel(net.swinViT.layers4[0].blocks[0].mlp.linear1.weight.grad, gn["d_l4_fc"]) < 5e-3
+        for p in net.parameters():
+            p.grad = None
+    gl = torch.Generator().manual_seed(3)
+    y = torch.randint(0, 3, (1, 1, 64, 64, 64), generator=gl).float()
+    out_ref = ref((x, None, None))
+    loss_ref = dice_ce_loss(out_ref, y)
+    loss_ref.backward()
+    out = net((x.to(DEV), None, None))
+    loss = DiceCELoss()(out, y.to(DEV))
+    loss.backward()
+    err = _rel(out, out_ref.detach().numpy())
+    pr = dict(ref.named_parameters())
+    num = den = 0.0
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        num += float(((p.grad.cpu() - pr[name].grad) ** 2).sum())
+        den += float((pr[name].grad ** 2).sum())
+    tot = (num / den) ** 0.5
+    print(f"[{dtype}] official Swin-UNETR 64^3: logits err/scale {err:.3e}, grad rel-L2 {tot:.3e}")
+    if dtype == torch.float32:
+        assert err < 2e-4 and abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4 and tot < 2e-3
+    else:
+        assert err < 0.08 and abs(float(loss.detach()) - float(loss_ref.detach())) < 3e-2 and tot < 0.15

@@ -172,3 +172,36 @@ def test_postproc_oracle(golden_dir):
     np.testing.assert_array_equal(majority_vote(folds, 4).ravel(), [1, 0, 1, 3, 2])
     x = rng.standard_normal((3, 4, 5, 6)).astype(np.float32)
     np.testing.assert_array_equal(argmax_labels(x), x.argmax(0).astype(np.uint8))
+
+
+def test_swin_official_vs_reference_file(golden_dir):
+    """oracle/swin_official.py against the reference's own swin_unetr_official.py (vendored MONAI SwinUNETR, run by
+    oracle/gen_golden.py): encoder features + gradients at 28^3 (padded 7-windows, clamped windows with the sliced index,
+    duplicated-sub-grid patch merging, un-affine proj_out) and the whole network at 64^3"""
+    from oracle import swin_official as so
+    g = _load(golden_dir, "swin_official_encoder.npz")
+    vit = so.SwinTransformer(1, 24, (7, 7, 7), (2, 2, 2), (2, 2, 2, 2), (3, 6, 12, 24))
+    det_fill_(vit, "swo_vit.")
+    x = det_tensor("swo_x28", (1, 1, 28, 28, 28)).requires_grad_(True)
+    outs = vit(x, True)
+    for i, o in enumerate(outs):
+        _close(o, g[f"out{i}"], rtol=1e-3, atol=1e-4)
+    sum((o * det_tensor(f"swo_r{i}", o.shape)).sum() for i, o in enumerate(outs)).backward()
+    blk = vit.layers1[0].blocks[1]
+    _close(x.grad, g["dx"], rtol=1e-3, atol=1e-3)
+    _close(blk.attn.qkv.weight.grad, g["d_qkv_w"], rtol=1e-3, atol=2e-2)
+    _close(blk.attn.qkv.bias.grad, g["d_qkv_b"], rtol=1e-3, atol=2e-2)
+    _close(blk.attn.relative_position_bias_table.grad, g["d_table"], rtol=1e-3, atol=1e-2)
+    _close(vit.layers1[0].downsample.reduction.weight.grad, g["d_merge_w"], rtol=1e-3, atol=1e-2)
+    _close(vit.layers2[0].blocks[1].attn.relative_position_bias_table.grad, g["d_table_l2"], rtol=1e-3, atol=1e-2)
+    gn = _load(golden_dir, "swin_official_net.npz")
+    net = so.SwinUNETR((64, 64, 64), 1, 3, feature_size=12)
+    det_fill_(net, "swo_net.")
+    y = net(det_tensor("swo_x64", (1, 1, 64, 64, 64)))
+    _close(y[:, :, ::2, ::2, ::2], gn["logits_s2"], rtol=1e-3, atol=1e-4)
+    assert abs(float(y.double().sum()) - float(gn["logits_sum"])) < 1e-3 * float(gn["logits_abs"])
+    (y * det_tensor("swo_ry", y.shape)).sum().backward()
+    _close(net.out.conv.conv.weight.grad, gn["d_out_w"], rtol=1e-3, atol=1e-2)
+    _close(net.encoder1.layer.conv1.conv.weight.grad, gn["d_enc1_w"], rtol=1e-3, atol=1e-2)
+    _close(net.swinViT.patch_embed.proj.weight.grad, gn["d_patch_w"], rtol=2e-3, atol=2e-2)
+    _close(net.swinViT.layers4[0].blocks[0].mlp.linear1.weight.grad, gn["d_l4_fc"], rtol=2e-3, atol=2e-2)
