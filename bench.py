@@ -39,6 +39,12 @@ WORK = {
                    "metric": "96^3 vols/sec fwd+bwd (train), Swin-UNETR-48",
                    "name": "Swin-UNETR 48-feat (reference encoder swin_nnformer: depths 2-2-2-2, heads 3-6-12-24, windows 6-6-6-3, "
                            "patch 2 + UNETR decoder) 1->{c}cls, {s}^3 patches, DiceCE + AdamW, per-GPU batch {b}"},
+    # MONAI / official variant (window 7 on a 49^3 padded token grid): the conv decoder dominates as above; the attention
+    # and MLP FLOPs differ by < 2 % of the total, the SwinUNETRCustom figure is kept as the algorithmic model
+    "swin_unetr_official": {"gflop_per_vol": 3 * 631.0, "gb_per_vol_bf16": 3 * 1.88,
+                            "metric": "96^3 vols/sec fwd+bwd (train), Swin-UNETR-48 (MONAI / official variant)",
+                            "name": "Swin-UNETR 48-feat (models/segmentors/swin_unetr_official.py: window 7, depths 2-2-2-2, heads "
+                                    "3-6-12-24, Linear patch merging) 1->{c}cls, {s}^3 patches, DiceCE + AdamW, per-GPU batch {b}"},
     "sliding_window": {"gflop_per_vol": 252.4e3, "gb_per_vol_bf16": 714.0,
                        "metric": "512^3 sliding-window vols/sec",
                        "name": "UNet base 1->{c}cls, {v}^3 volume, roi {s}^3, overlap 0.5, gaussian, {w} windows, sw_batch {b}"},
@@ -85,6 +91,10 @@ def cpu_baseline_train(workload, batch, size, n_cls, budget_s=25.0):
         from oracle.blocks import BasicUNet
         net = BasicUNet(1, n_cls)
         what = "oracle/ BasicUNet"
+    elif workload == "swin_unetr_official":
+        from oracle import swin_official as O
+        net = O.SwinUNETR((size,) * 3, 1, n_cls, feature_size=48)
+        what = "oracle/ swin_official.SwinUNETR(48)"
     else:
         from oracle import swin as O
         net = O.SwinUNETRCustom(O.SwinTransformerNNFormer((size,) * 3), 1, n_cls, 48, 2)
@@ -256,7 +266,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU replay structure (graph A | eager gap | graph B)")
-    ap.add_argument("--workload", default="unet", choices=["unet", "swin_unetr", "sliding_window"],
+    ap.add_argument("--workload", default="unet", choices=["unet", "swin_unetr", "swin_unetr_official", "sliding_window"],
                     help="unet = the headline (BASELINE configs[1]); swin_unetr = configs[3]; sliding_window = configs[4]")
     ap.add_argument("--sw-size", type=int, default=512)
     ap.add_argument("--sw-batch", type=int, default=8)   # windows per forward
@@ -292,6 +302,10 @@ def main():
                                       drop_path_rate=0.0, compute_dtype=dtype)
         net = SwinUNETRCustom(enc, 1, args.classes, (args.size,) * 3, 48, (2, 2, 2), compute_dtype=dtype).to(dev)
         args.no_graph = args.no_graph or bool(os.environ.get("MSSEG_SWIN_NO_GRAPH"))
+    elif args.workload == "swin_unetr_official":
+        from medicalsemseg_amd.models.swin_unetr_official import SwinUNETR
+        net = SwinUNETR((args.size,) * 3, 1, args.classes, feature_size=48, compute_dtype=dtype).to(dev)
+        args.no_graph = True     # torch pad / slice / cat ops of the window padding and patch merging stay eager
     else:
         net = UNet(1, args.classes, compute_dtype=dtype).to(dev)
     opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=4e-4, betas=(0.9, 0.95), eps=1e-6)

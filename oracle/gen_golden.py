@@ -314,17 +314,17 @@ def gen_swin_official():
           d_table=blk.attn.relative_position_bias_table.grad, d_merge_w=vit.layers1[0].downsample.reduction.weight.grad,
           d_table_l2=vit.layers2[0].blocks[1].attn.relative_position_bias_table.grad,
           **{f"out{i}": o for i, o in enumerate(outs)})
-    # (b) the whole network at 64^3 (the deepest feature map must keep more than one voxel for InstanceNorm), feature size 12
-    net = R.SwinUNETR(img_size=(64, 64, 64), in_channels=1, out_channels=3, feature_size=12)
+    # (b) the whole network at 64^3 (the deepest feature map must keep more than one voxel for InstanceNorm), feature size 24 (head dim 8)
+    net = R.SwinUNETR(img_size=(64, 64, 64), in_channels=1, out_channels=3, feature_size=24)
     det_fill_(net, "swo_net.")
     x2 = det_tensor("swo_x64", (1, 1, 64, 64, 64))
     y = net(x2)
     (y * det_tensor("swo_ry", y.shape)).sum().backward()
     _save("swin_official_net.npz", logits_s2=y[:, :, ::2, ::2, ::2], logits_sum=y.double().sum(), logits_abs=y.double().abs().sum(),
           d_out_w=net.out.conv.conv.weight.grad,
-          d_enc1_w=net.encoder1.layer.conv1.conv.weight.grad,
+          d_enc1_w=net.encoder1.layer.conv1.conv.weight.grad[:12],
           d_patch_w=net.swinViT.patch_embed.proj.weight.grad,
-          d_l4_fc=net.swinViT.layers4[0].blocks[0].mlp.linear1.weight.grad)
+          d_l4_fc=net.swinViT.layers4[0].blocks[0].mlp.linear1.weight.grad[:96, :96])
 
 
 def main():

@@ -206,16 +206,16 @@ def test_swin_official_encoder_vs_reference_golden(golden_dir):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_swin_official_net_vs_reference_golden_and_oracle(golden_dir, dtype):
-    """whole official Swin-UNETR (feature 12, 64^3): logits / gradients against the reference-file golden (fp32) and
+    """whole official Swin-UNETR (feature 24, 64^3): logits / gradients against the reference-file golden (fp32) and
     against the oracle restatement on random labels with DiceCE (both dtypes)"""
     from medicalsemseg_amd.losses import DiceCELoss
     from medicalsemseg_amd.models.swin_unetr_official import SwinUNETR
     from oracle import swin_official as O
     from oracle.losses import dice_ce_loss
     gn = _load(golden_dir, "swin_official_net.npz")
-    ref = O.SwinUNETR((64, 64, 64), 1, 3, feature_size=12)
+    ref = O.SwinUNETR((64, 64, 64), 1, 3, feature_size=24)
     det_fill_(ref, "swo_net.")
-    net = SwinUNETR((64, 64, 64), 1, 3, feature_size=12, compute_dtype=dtype)
+    net = SwinUNETR((64, 64, 64), 1, 3, feature_size=24, compute_dtype=dtype)
     assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
     net.load_state_dict(ref.state_dict(), strict=True)
     net = net.to(DEV)
@@ -225,9 +225,9 @@ def test_swin_official_net_vs_reference_golden_and_oracle(golden_dir, dtype):
         assert _rel(out[:, :, ::2, ::2, ::2], gn["logits_s2"]) < 2e-4
         (out * det_tensor("swo_ry", tuple(out.shape)).to(DEV)).sum().backward()
         assert _rel(net.out.conv.conv.weight.grad, gn["d_out_w"]) < 2e-3
-        assert _rel(net.encoder1.layer.conv1.conv.weight.grad, gn["d_enc1_w"]) < 2e-3
+        assert _rel(net.encoder1.layer.conv1.conv.weight.grad[:12], gn["d_enc1_w"]) < 2e-3
         assert _rel(net.swinViT.patch_embed.proj.weight.grad, gn["d_patch_w"]) < 5e-3
-        assert _rel(net.swinViT.layers4[0].blocks[0].mlp.linear1.weight.grad, gn["d_l4_fc"]) < 5e-3
+        assert _rel(net.swinViT.layers4[0].blocks[0].mlp.linear1.weight.grad[:96, :96], gn["d_l4_fc"]) < 5e-3
         for p in net.parameters():
             p.grad = None
     gl = torch.Generator().manual_seed(3)
