@@ -389,6 +389,18 @@ int msseg_resample_nearest_u8(const uint8_t* src, int SD, int SH, int SW, uint8_
                               msseg_stream_t stream);
 int msseg_majority_vote_u8(const uint8_t* labels, int F, long long V, int C, uint8_t* out, msseg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Device-side training crop + augmentation (the step right before the path): one gather launch per
+ * batch of patches from a volume cached in HBM.  Replaces RandCropByPosNegLabeld + RandFlipd x3 + RandRotate90d +
+ * RandShiftIntensityd + RandScaleIntensityd (data/dataset_builder.py:108-193); the random draws arrive in `table`.
+ * img: fp32 [C][VD][VH][VW]; lab: uint8 [VD][VH][VW] or NULL; out_img: [npatch][C][R][R][R] (out_dtype), out_lab: fp32
+ * [npatch][1][R][R][R].  Row: crop start (z0, y0, x0), flips bit0/1/2 = axis d/h/w, rotk = quarter turns in the (d, h)
+ * plane (np.rot90 sense), image value = (v + shift) * scale.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct msseg_aug_row { int32_t z0, y0, x0, flips, rotk, pad0; float shift, scale; } msseg_aug_row;
+int msseg_aug_crop_batch(const float* img, const uint8_t* lab, int C, int VD, int VH, int VW, const void* table,
+                         int npatch, void* out_img, int out_dtype, float* out_lab, int R, msseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

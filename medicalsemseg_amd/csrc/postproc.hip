@@ -125,3 +125,66 @@ int msseg_majority_vote_u8(const uint8_t* labels, int F, long long V, int C, uin
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Device-side training crop + augmentation on a cached volume: replaces the CPU chain
+// RandCropByPosNegLabeld -> RandFlipd x3 -> RandRotate90d -> RandShiftIntensityd -> RandScaleIntensityd
+// (/root/reference/data/dataset_builder.py:108-193, data/transforms.py:264-419) for volumes resident in HBM.
+// The random draws are made on the host (a few numbers per patch) and arrive as a parameter table; the kernel is a
+// pure gather: out[b][c][o] = (img[c][src(o)] + shift) * scale for the image channels, lab[src(o)] for the label,
+// with src(o) = crop start + the inverse of (flip d, flip h, flip w, rot90^k in the (d, h) plane) applied to o.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct AugRow { int z0, y0, x0, flips, rotk, pad0; float shift, scale; };   // 32 bytes, mirrors msseg_aug_row
+
+template <typename TO>
+__global__ __launch_bounds__(256) void aug_crop_kernel(const float* __restrict__ img, const unsigned char* __restrict__ lab,
+                                                       int C, int VD, int VH, int VW, const AugRow* __restrict__ table,
+                                                       TO* __restrict__ out_img, float* __restrict__ out_lab, int R) {
+#pragma clang fp contract(off)   // (v + shift) * scale with two roundings, as the two numpy transforms apply them
+    const AugRow row = table[blockIdx.y];
+    const long long R3 = (long long)R * R * R, V = (long long)VD * VH * VW;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < R3; i += (long long)gridDim.x * 256) {
+        int x = (int)(i % R), y = (int)((i / R) % R), z = (int)(i / ((long long)R * R));
+        // undo rot90^k in the (z, y) plane: out[i, j] = m[j, n-1-i] (k = 1), m[n-1-i, n-1-j] (2), m[n-1-j, i] (3)
+        int sz = z, sy = y;
+        if (row.rotk == 1) { sz = y; sy = R - 1 - z; }
+        else if (row.rotk == 2) { sz = R - 1 - z; sy = R - 1 - y; }
+        else if (row.rotk == 3) { sz = R - 1 - y; sy = z; }
+        int sx = x;
+        if (row.flips & 1) sz = R - 1 - sz;
+        if (row.flips & 2) sy = R - 1 - sy;
+        if (row.flips & 4) sx = R - 1 - sx;
+        const long long v = ((long long)(row.z0 + sz) * VH + (row.y0 + sy)) * VW + (row.x0 + sx);
+        for (int c = 0; c < C; ++c) {
+            const float a = img[(long long)c * V + v] + row.shift;
+            const float b = a * row.scale;
+            if constexpr (sizeof(TO) == 4) out_img[((long long)blockIdx.y * C + c) * R3 + i] = b;
+            else out_img[((long long)blockIdx.y * C + c) * R3 + i] = (TO)b;
+        }
+        if (lab) out_lab[(long long)blockIdx.y * R3 + i] = (float)lab[v];
+    }
+}
+
+}  // namespace
+
+extern "C" int msseg_aug_crop_batch(const float* img, const uint8_t* lab, int C, int VD, int VH, int VW,
+                                    const void* table, int npatch, void* out_img, int out_dtype, float* out_lab, int R,
+                                    msseg_stream_t stream) {
+    if (!img || !table || !out_img || C < 1 || npatch < 1 || npatch > 65535 || R < 1 || R > VD || R > VH || R > VW)
+        MSSEG_FAIL(MSSEG_EINVAL, "aug_crop_batch: bad args (cubic roi %d inside volume %dx%dx%d)", R, VD, VH, VW);
+    if ((lab == nullptr) != (out_lab == nullptr)) MSSEG_FAIL(MSSEG_EINVAL, "aug_crop_batch: lab and out_lab go together");
+    long long gx = ceil_div_ll((long long)R * R * R, 256LL * 4);
+    if (gx > 4096) gx = 4096;
+    dim3 grid((unsigned)gx, npatch);
+    if (out_dtype == MSSEG_F32)
+        hipLaunchKernelGGL(aug_crop_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, lab, C, VD, VH, VW,
+                           (const AugRow*)table, (float*)out_img, out_lab, R);
+    else if (out_dtype == MSSEG_BF16)
+        hipLaunchKernelGGL(aug_crop_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, img, lab, C, VD, VH, VW,
+                           (const AugRow*)table, (bf16_t*)out_img, out_lab, R);
+    else MSSEG_FAIL(MSSEG_EINVAL, "aug_crop_batch: bad dtype");
+    MSSEG_CHECK_LAUNCH("aug_crop_batch");
+    return MSSEG_OK;
+}

@@ -101,6 +101,7 @@ SIGNATURES = {
     "msseg_argmax_u8": ([_vp, _i, _ll, _vp, _vp], _i),
     "msseg_resample_nearest_u8": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _vp], _i),
     "msseg_majority_vote_u8": ([_vp, _i, _ll, _i, _vp, _vp], _i),
+    "msseg_aug_crop_batch": ([_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp], _i),
     "msseg_sw_gather_batch": ([_vp, _ll, _vp, _ll, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
     "msseg_sw_blend_batch": ([_vp, _ll, _i, _vp, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
 }
@@ -853,6 +854,17 @@ def majority_vote_u8(labels: torch.Tensor, n_classes: int) -> torch.Tensor:
     _ck(lib().msseg_majority_vote_u8(_p(labels), labels.shape[0], out.numel(), n_classes, _p(out), _stream()),
         "majority_vote_u8")
     return out
+
+
+def aug_crop_batch(img, lab, table, out_img, out_lab, roi):
+    """img fp32 [C, D, H, W]; lab uint8 [D, H, W] or None; table: uint8 device tensor of npatch msseg_aug_row structs"""
+    _need_gpu(img, table, out_img)
+    assert img.dtype == torch.float32 and img.is_contiguous() and out_img.is_contiguous()
+    npatch = out_img.shape[0]
+    assert table.numel() >= npatch * 32
+    _ck(lib().msseg_aug_crop_batch(_p(img), _p(lab), img.shape[0], img.shape[1], img.shape[2], img.shape[3], _p(table),
+                                   npatch, _p(out_img), dt(out_img), _p(out_lab), roi, _stream()), "aug_crop_batch")
+    return out_img, out_lab
 
 
 # --------------------------------------------------------------------------------------------
