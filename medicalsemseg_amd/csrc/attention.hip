@@ -511,7 +511,7 @@ int msseg_window_attention_fwd2(const void* qkv, const float* qkv_bias, const fl
     p.qkv = qkv; p.qkv_bias = qkv_bias; p.table = table; p.out = out; p.lse = lse;
     const size_t smem = (size_t)p.N * p.hd * 2 * 4 + (size_t)p.M3 * 4 + (size_t)p.N * 3 * 4;
     if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd: window too large for LDS");
-    if (dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 224 && p.M3 <= 2047 && p.bws == p.ws && (C % 8) == 0 &&
+    if (dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 352 && p.M3 <= 4095 && p.bws == p.ws && (C % 8) == 0 &&
         !getenv("MSSEG_ATTN_NO_MFMA")) {
         // bf16: QK^T and PV on the matrix cores (attention_mfma.hip)
         return msseg_window_attention_fwd_mfma(p, (hipStream_t)stream);
@@ -524,7 +524,7 @@ int msseg_window_attention_fwd2(const void* qkv, const float* qkv_bias, const fl
 }
 
 static bool attn_bwd_on_mfma(const AttnParams& p, int C, int dtype) {
-    return dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 224 && p.M3 <= 2047 && p.bws == p.ws && (C % 8) == 0 &&
+    return dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 352 && p.M3 <= 4095 && p.bws == p.ws && (C % 8) == 0 &&
            !getenv("MSSEG_ATTN_NO_MFMA") && !getenv("MSSEG_ATTN_BWD_NO_MFMA");
 }
 

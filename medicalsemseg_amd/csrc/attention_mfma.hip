@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const AttnParams
     bf16_t* vT = kS + NP * HD;                     // [HD][NP]   (transposed)
     float* tabS = (float*)(vT + HD * NP);          // [M3]
     int* tok = (int*)(tabS + p.M3);                // [NP]
-    unsigned short* kinfo = (unsigned short*)(tok + NP);  // [NP]  code | region << 11 ; 0xFFFF = padded key
+    unsigned int* kinfo = (unsigned int*)(tok + NP);  // [NP]  code | region << 12 ; 0xFFFFFFFF = padded key
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -47,10 +47,10 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const AttnParams
             if (i < p.N) {
                 int rg, cd;
                 tok[i] = window_token(p, wz, wy, wx, i, rg, cd);
-                kinfo[i] = (unsigned short)(cd | (rg << 11));
+                kinfo[i] = (unsigned int)(cd | (rg << 12));
             } else {
                 tok[i] = -2;            // padded row of the MFMA tile (not a token)
-                kinfo[i] = 0xFFFF;
+                kinfo[i] = 0xFFFFFFFFu;
             }
         }
         for (int h = 0; h < p.heads; ++h) {
@@ -82,68 +82,95 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const AttnParams
             __syncthreads();
             for (int qt = wave; qt < NKT; qt += 4) {
                 const int qi = qt * 32 + r;              // this lane's query (column of every X tile)
-                const unsigned short qinfo = kinfo[qi];
-                const int qcode = (qinfo == 0xFFFF ? 0 : (qinfo & 2047)) + off, qreg = qinfo >> 11;  // padded query rows: any valid code
+                const unsigned int qinfo = kinfo[qi];
+                const int qcode = (qinfo == 0xFFFFFFFFu ? 0 : (qinfo & 4095)) + off, qreg = qinfo >> 12;  // padded query rows: any valid code
                 // ---- X_j = K_j Q_i^T ----
                 bf16x8_t qf[KS];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) qf[s] = *(const bf16x8_t*)(qS + qi * HD + s * 16 + hh * 8);
-                f32x16_t X[NKT];
-#pragma unroll
-                for (int j = 0; j < NKT; ++j) {
-                    f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        const bf16x8_t kf = *(const bf16x8_t*)(kS + (j * 32 + r) * HD + s * 16 + hh * 8);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], acc, 0, 0, 0);
-                    }
-                    X[j] = acc;
-                }
-                // ---- scores: scale, relative-position bias, shift mask, key padding; row max ----
-                float mx = -INFINITY;
-#pragma unroll
-                for (int j = 0; j < NKT; ++j)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        const int key = j * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
-                        const unsigned short ki = kinfo[key];
-                        float sc;
-                        if (ki == 0xFFFF) sc = -INFINITY;
-                        else {
-                            sc = X[j][g] * p.scale + tabS[qcode - (ki & 2047)];
-                            if (p.use_mask && (ki >> 11) != qreg) sc += -100.f;
-                        }
-                        X[j][g] = sc;
-                        mx = fmaxf(mx, sc);
-                    }
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                float l = 0.f;
-#pragma unroll
-                for (int j = 0; j < NKT; ++j)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        const float pe = __expf(X[j][g] - mx);
-                        X[j][g] = pe;
-                        l += pe;
-                    }
-                l += __shfl_xor(l, 32);
-                // ---- O^T += V^T_j P_j  (P_j straight from the accumulator registers) ----
+                // keys in chunks of JC tiles (one chunk up to 7 tiles; 343-token windows take two, with the running max /
+                // sum rescale of an online softmax -- the query sits on the lane, so the rescale is a per-lane scalar)
+                constexpr int JC = NKT <= 7 ? NKT : 4;
+                float mx = -INFINITY, l = 0.f;
                 f32x16_t Y = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const int vrow = r & (HD - 1);   // rows >= HD of the 32-row A tile are don't-care
+                constexpr int UNR_CHUNKS = JC < NKT ? 1 : 2;   // several chunks: keep ONE chunk's scores live
+#pragma unroll UNR_CHUNKS
+                for (int j0 = 0; j0 < NKT; j0 += JC) {
+                    f32x16_t X[JC];
 #pragma unroll
-                for (int j = 0; j < NKT; ++j)
+                    for (int jj = 0; jj < JC; ++jj) {
+                        const int j = j0 + jj;
+                        f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        if (j < NKT) {
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        bf16x8_t pf;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)X[j][8 * s + e];
-                        // element e of lane-half hh of P's fragment is key row 16s + 8(e>>2) + 4hh + (e&3) of tile j
-                        const bf16_t* vp = vT + vrow * NP + j * 32 + 16 * s + 4 * hh;
-                        const bf16x4_t v0 = *(const bf16x4_t*)vp;
-                        const bf16x4_t v1 = *(const bf16x4_t*)(vp + 8);
-                        const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, Y, 0, 0, 0);
+                            for (int s = 0; s < KS; ++s) {
+                                const bf16x8_t kf = *(const bf16x8_t*)(kS + (j * 32 + r) * HD + s * 16 + hh * 8);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], acc, 0, 0, 0);
+                            }
+                        }
+                        X[jj] = acc;
                     }
+                    // ---- scores: scale, relative-position bias, shift mask, key padding; chunk max ----
+                    float mc = -INFINITY;
+#pragma unroll
+                    for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) {
+                            const int j = j0 + jj;
+                            const int key = j * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                            const unsigned int ki = j < NKT ? kinfo[key] : 0xFFFFFFFFu;
+                            float sc;
+                            if (ki == 0xFFFFFFFFu) sc = -INFINITY;
+                            else {
+                                sc = X[jj][g] * p.scale + tabS[qcode - (ki & 4095)];
+                                if (p.use_mask && (ki >> 12) != qreg) sc += -100.f;
+                            }
+                            X[jj][g] = sc;
+                            mc = fmaxf(mc, sc);
+                        }
+                    mc = fmaxf(mc, __shfl_xor(mc, 32));
+                    if constexpr (JC < NKT) {
+                        const float mnew = fmaxf(mx, mc);
+                        const float alpha = __expf(mx - mnew);     // 0 for the first chunk (mx = -inf)
+                        l *= alpha;
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) Y[g] *= alpha;
+                        mx = mnew;
+                    } else {
+                        mx = mc;
+                    }
+                    float lc = 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) {
+                            const float pe = __expf(X[jj][g] - mx);
+                            X[jj][g] = pe;
+                            lc += pe;
+                        }
+                    lc += __shfl_xor(lc, 32);
+                    l += lc;
+                    // ---- O^T += V^T_j P_j  (P_j straight from the accumulator registers) ----
+#pragma unroll
+                    for (int jj = 0; jj < JC; ++jj) {
+                        const int j = j0 + jj;
+                        if (j < NKT) {
+#pragma unroll
+                            for (int s = 0; s < 2; ++s) {
+                                bf16x8_t pf;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)X[jj][8 * s + e];
+                                // element e of lane-half hh of P's fragment is key row 16s + 8(e>>2) + 4hh + (e&3) of tile j
+                                const bf16_t* vp = vT + vrow * NP + j * 32 + 16 * s + 4 * hh;
+                                const bf16x4_t v0 = *(const bf16x4_t*)vp;
+                                const bf16x4_t v1 = *(const bf16x4_t*)(vp + 8);
+                                const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                                Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, Y, 0, 0, 0);
+                            }
+                        }
+                    }
+                }
                 // ---- store: lane = query, registers = head-dim rows (reg&3) + 8*(reg>>2) + 4*hh ----
                 const int tk = tok[qi];
                 const float inv = 1.f / l;
@@ -194,7 +221,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
     float* tabS = delS + NP;                       // [M3]
     float* dtabS = tabS + p.M3;                    // [M3]
     int* tok = (int*)(dtabS + p.M3);               // [NP]
-    unsigned short* kinfo = (unsigned short*)(tok + NP);  // [NP] code | region << 11 ; 0xFFFF = padded row of the tile
+    unsigned int* kinfo = (unsigned int*)(tok + NP);  // [NP] code | region << 12 ; 0xFFFFFFFF = padded row of the tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -217,10 +244,10 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
             if (i < p.N) {
                 int rg, cd;
                 tok[i] = window_token(p, wz, wy, wx, i, rg, cd);
-                kinfo[i] = (unsigned short)(cd | (rg << 11));
+                kinfo[i] = (unsigned int)(cd | (rg << 12));
             } else {
                 tok[i] = -2;
-                kinfo[i] = 0xFFFF;
+                kinfo[i] = 0xFFFFFFFFu;
             }
         }
         for (int h = 0; h < p.heads; ++h) {
@@ -272,9 +299,9 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
             // ------------------------------ pass 1: dQ (+ dtable) ------------------------------
             for (int qt = wave; qt < NKT; qt += 4) {
                 const int qi = qt * 32 + r;
-                const unsigned short qinfo = kinfo[qi];
+                const unsigned int qinfo = kinfo[qi];
                 const bool qlive = tok[qi] >= 0;
-                const int qcode = (qinfo == 0xFFFF ? 0 : (qinfo & 2047)) + off, qreg = qinfo >> 11;
+                const int qcode = (qinfo == 0xFFFFFFFFu ? 0 : (qinfo & 4095)) + off, qreg = qinfo >> 12;
                 const float lq = lseS[qi], dq_del = delS[qi];
                 bf16x8_t qf[KS], of[KS];
 #pragma unroll
@@ -300,14 +327,14 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int key = j * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
-                        const unsigned short ki = kinfo[key];
+                        const unsigned int ki = kinfo[key];
                         float ds = 0.f;
                         // (a padded query's dQ row is never written, so with DSWS its dS may be zeroed here: the stored
                         // tile then holds exactly the table-gradient contributions)
-                        if (ki != 0xFFFF && qinfo != 0xFFFF && (!DSWS || qlive)) {
-                            const int ti = qcode - (ki & 2047);
+                        if (ki != 0xFFFFFFFFu && qinfo != 0xFFFFFFFFu && (!DSWS || qlive)) {
+                            const int ti = qcode - (ki & 4095);
                             float sc = X[g] * p.scale + tabS[ti];
-                            if (p.use_mask && (ki >> 11) != qreg) sc += -100.f;
+                            if (p.use_mask && (ki >> 12) != qreg) sc += -100.f;
                             const float pr = __expf(sc - lq);
                             ds = pr * (DP[g] - dq_del);
                             if (!DSWS && p.dtable && qlive) atomicAdd(&dtabS[ti], ds);
@@ -341,8 +368,8 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
             // ------------------------------ pass 2: dK, dV ------------------------------
             for (int jt = wave; jt < NKT; jt += 4) {
                 const int kj = jt * 32 + r;
-                const unsigned short kinf = kinfo[kj];
-                const int kcode = (kinf == 0xFFFF) ? 0 : (kinf & 2047), kreg = kinf >> 11;
+                const unsigned int kinf = kinfo[kj];
+                const int kcode = (kinf == 0xFFFFFFFFu) ? 0 : (kinf & 4095), kreg = kinf >> 12;
                 bf16x8_t kf[KS], vf[KS];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
@@ -368,11 +395,11 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int qrow = i * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
-                        const unsigned short qi2 = kinfo[qrow];
+                        const unsigned int qi2 = kinfo[qrow];
                         float pr = 0.f, ds = 0.f;
-                        if (qi2 != 0xFFFF && kinf != 0xFFFF && tok[qrow] >= 0) {   // padded queries get no gradient
-                            float sc = X[g] * p.scale + tabS[(qi2 & 2047) + off - kcode];
-                            if (p.use_mask && (qi2 >> 11) != kreg) sc += -100.f;
+                        if (qi2 != 0xFFFFFFFFu && kinf != 0xFFFFFFFFu && tok[qrow] >= 0) {   // padded queries get no gradient
+                            float sc = X[g] * p.scale + tabS[(qi2 & 4095) + off - kcode];
+                            if (p.use_mask && (qi2 >> 12) != kreg) sc += -100.f;
                             pr = __expf(sc - lseS[qrow]);
                             ds = pr * (DP[g] - delS[qrow]);
                         }
@@ -489,7 +516,7 @@ constexpr int DS_GROUPS = 8;
 
 template <int HD, int NKT> int launch_bwd(const AttnParams& p, hipStream_t stream) {
     constexpr int NP = NKT * 32;
-    const size_t smem = (size_t)7 * NP * HD * 2 + (size_t)2 * NP * 4 + (size_t)2 * p.M3 * 4 + (size_t)NP * 4 + (size_t)NP * 2 + 16;
+    const size_t smem = (size_t)7 * NP * HD * 2 + (size_t)2 * NP * 4 + (size_t)2 * p.M3 * 4 + (size_t)NP * 4 + (size_t)NP * 4 + 16;
     const bool dsws = p.ds_ws != nullptr && p.dtable != nullptr;
     auto kern = dsws ? win_attn_bwd_mfma_kernel<HD, NKT, true> : win_attn_bwd_mfma_kernel<HD, NKT, false>;
     static bool attr_set[2] = {false, false};
@@ -521,13 +548,24 @@ template <int HD> int launch_bwd_hd(const AttnParams& p, hipStream_t stream) {
     if (nkt == 1) return launch_bwd<HD, 1>(p, stream);
     if (nkt == 2) return launch_bwd<HD, 2>(p, stream);
     if (nkt <= 4) return launch_bwd<HD, 4>(p, stream);
-    return launch_bwd<HD, 7>(p, stream);
+    if (nkt <= 7) return launch_bwd<HD, 7>(p, stream);
+    return launch_bwd<HD, 11>(p, stream);
 }
 
 template <int HD, int NKT> int launch(const AttnParams& p, hipStream_t stream) {
     constexpr int NP = NKT * 32;
-    const size_t smem = (size_t)3 * NP * HD * 2 + (size_t)p.M3 * 4 + (size_t)NP * 4 + (size_t)NP * 2 + 16;
+    const size_t smem = (size_t)3 * NP * HD * 2 + (size_t)p.M3 * 4 + (size_t)NP * 4 + (size_t)NP * 4 + 16;
     int gx = p.nwin_total < msseg_num_cus() * 4 ? p.nwin_total : msseg_num_cus() * 4;
+    if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd_mfma: window too large for LDS (%zu bytes)", smem);
+    if (smem > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)win_attn_fwd_mfma_kernel<HD, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess)
+                MSSEG_FAIL(MSSEG_ELAUNCH, "window_attention_fwd_mfma: cannot set dynamic LDS size");
+            attr_set = true;
+        }
+    }
     hipLaunchKernelGGL((win_attn_fwd_mfma_kernel<HD, NKT>), dim3(gx), dim3(256), smem, stream, p);
     MSSEG_CHECK_LAUNCH("window_attention_fwd_mfma");
     return MSSEG_OK;
@@ -538,14 +576,15 @@ template <int HD> int launch_hd(const AttnParams& p, hipStream_t stream) {
     if (nkt == 1) return launch<HD, 1>(p, stream);
     if (nkt == 2) return launch<HD, 2>(p, stream);
     if (nkt <= 4) return launch<HD, 4>(p, stream);
-    return launch<HD, 7>(p, stream);
+    if (nkt <= 7) return launch<HD, 7>(p, stream);
+    return launch<HD, 11>(p, stream);     // window 7: 343 tokens (MONAI Swin-UNETR)
 }
 
 }  // namespace
 
 static int bwd_nkt(const AttnParams& p) {   // the NKT instantiation launch_bwd_hd picks
     const int nkt = (p.N + 31) / 32;
-    return nkt == 1 ? 1 : (nkt == 2 ? 2 : (nkt <= 4 ? 4 : 7));
+    return nkt == 1 ? 1 : (nkt == 2 ? 2 : (nkt <= 4 ? 4 : (nkt <= 7 ? 7 : 11)));
 }
 
 static int ds_groups_for(const AttnParams& p) { return p.nwin_total < DS_GROUPS ? p.nwin_total : DS_GROUPS; }
@@ -563,11 +602,11 @@ void msseg_window_attention_bwd_mfma_carve(AttnParams& p, void* workspace) {
 }
 
 int msseg_window_attention_bwd_mfma(const AttnParams& p, hipStream_t stream) {
-    if (p.M3 > 2047 || p.N > 224) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd_mfma: window too large");
+    if (p.M3 > 4095 || p.N > 352) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd_mfma: window too large");
     return p.hd == 16 ? launch_bwd_hd<16>(p, stream) : launch_bwd_hd<32>(p, stream);
 }
 
 int msseg_window_attention_fwd_mfma(const AttnParams& p, hipStream_t stream) {
-    if (p.M3 > 2047 || p.N > 224) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd_mfma: window too large");
+    if (p.M3 > 4095 || p.N > 352) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd_mfma: window too large");
     return p.hd == 16 ? launch_hd<16>(p, stream) : launch_hd<32>(p, stream);
 }

@@ -251,3 +251,34 @@ def test_swin_official_net_vs_reference_golden_and_oracle(golden_dir, dtype):
         assert err < 2e-4 and abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4 and tot < 2e-3
     else:
         assert err < 0.08 and abs(float(loss.detach()) - float(loss_ref.detach())) < 3e-2 and tot < 0.15
+
+
+@pytest.mark.parametrize("R,ws,heads,C,shift", [(12, 7, 3, 48, 3), (14, 7, 2, 64, 0), (9, 7, 3, 48, 3)])
+def test_window7_attention_mfma_equals_vector_kernels(monkeypatch, R, ws, heads, C, shift):
+    """343-token windows (MONAI Swin-UNETR): the bf16 MFMA kernels (11 key tiles, online-softmax chunks, 12-bit bias
+    codes) against the exact-fp32-math vector kernels on the same bf16 operands, forward and backward, with padding
+    (12 -> 14, 9 -> 14) and the shift mask"""
+    from medicalsemseg_amd import hip
+    torch.manual_seed(7)
+    qkv = (torch.randn(2, R, R, R, 3 * C, device=DEV) * 0.7).bfloat16()
+    qb = torch.randn(3 * C, device=DEV) * 0.3
+    tab = torch.randn((2 * ws - 1) ** 3, heads, device=DEV) * 0.3
+    dout = torch.randn(2, R, R, R, C, device=DEV).bfloat16()
+    res = []
+    for no_mfma in (False, True):
+        if no_mfma:
+            monkeypatch.setenv("MSSEG_ATTN_NO_MFMA", "1")
+        else:
+            monkeypatch.delenv("MSSEG_ATTN_NO_MFMA", raising=False)
+        out = torch.empty(2, R, R, R, C, device=DEV, dtype=torch.bfloat16)
+        lse = hip.window_attention_fwd(qkv, qb, tab, out, heads, ws, shift)
+        dqkv = torch.empty_like(qkv)
+        dtab = torch.zeros_like(tab)
+        hip.window_attention_bwd(qkv, qb, tab, out, lse, dout, dqkv, dtab, heads, ws, shift)
+        res.append((out.float(), lse.clone(), dqkv.float(), dtab.clone()))
+    monkeypatch.delenv("MSSEG_ATTN_NO_MFMA", raising=False)
+    (o0, l0, d0, t0), (o1, l1, d1, t1) = res
+    assert float((o0 - o1).abs().max()) / float(o1.abs().max()) < 2e-2
+    assert float((l0 - l1).abs().max()) < 2e-2
+    assert float((d0 - d1).norm() / d1.norm()) < 3e-2
+    assert float((t0 - t1).norm() / t1.norm()) < 3e-2
