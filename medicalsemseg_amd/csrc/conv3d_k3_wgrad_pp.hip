@@ -301,9 +301,6 @@ int msseg_k3wg_pp_grid(const K3WgParams& p) {
     const int tiles = p.N * ceil_div(p.D, TD) * ceil_div(p.H, TH) * ceil_div(p.W, TW);
     int gx = msseg_num_cus() / pairs;
     gx &= ~7;
-    static const int cap = getenv("MSSEG_K3WG_GXCAP") ? atoi(getenv("MSSEG_K3WG_GXCAP")) : 0;   // A/B: fewer slabs per pair
-    static const int cap_tiles = getenv("MSSEG_K3WG_GXCAP_TILES") ? atoi(getenv("MSSEG_K3WG_GXCAP_TILES")) : 4096;
-    if (cap > 0 && tiles <= cap_tiles && gx > cap) gx = cap;
     if (gx < 8) gx = 8;
     if (gx > tiles) gx = tiles;
     return gx;
