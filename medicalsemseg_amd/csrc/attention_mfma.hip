@@ -491,14 +491,14 @@ __global__ __launch_bounds__(256) void attn_dtable_gather_kernel(const float* __
     const int m = 2 * wsz - 1;
     const int dz = ti / (m * m) - (wsz - 1), dy = (ti / m) % m - (wsz - 1), dx = ti % m - (wsz - 1);
     float v = 0.f;
-    if (i < N) {
-        const int jz = i / (wsz * wsz) - dz, jy = (i / wsz) % wsz - dy, jx = i % wsz - dx;
+    for (int qi = i; qi < N; qi += 256) {     // windows of up to 352 tokens: a thread may own two queries
+        const int jz = qi / (wsz * wsz) - dz, jy = (qi / wsz) % wsz - dy, jx = qi % wsz - dx;
         if (jz >= 0 && jz < wsz && jy >= 0 && jy < wsz && jx >= 0 && jx < wsz) {
             const int j = (jz * wsz + jy) * wsz + jx;
             // fragment order of the backward kernel's pass 1: tile (i / 32, j / 32), lane = (i % 32) + 32 * hh,
             // register g with key offset (g & 3) + 8 * (g >> 2) + 4 * hh
             const int kk = j & 31, hh = (kk >> 2) & 1, g = (kk & 3) + 4 * (kk >> 3);
-            const long long e = ((long long)((i >> 5) * nkt + (j >> 5)) * 64 + (i & 31) + 32 * hh) * 16 + g;
+            const long long e = ((long long)((qi >> 5) * nkt + (j >> 5)) * 64 + (qi & 31) + 32 * hh) * 16 + g;
             const long long E = (long long)nkt * nkt * 1024;
             for (int q = 0; q < groups; ++q) v += psum[((long long)q * heads + h) * E + e];
         }
