@@ -524,6 +524,11 @@ int msseg_window_attention_fwd2(const void* qkv, const float* qkv_bias, const fl
 }
 
 static bool attn_bwd_on_mfma(const AttnParams& p, int C, int dtype) {
+    {   // LDS image of the MFMA backward (attention_mfma.hip launch_bwd): head dim 32 at 343 tokens does not fit
+        const int nkt = (p.N + 31) / 32;
+        const size_t np = (size_t)(nkt == 1 ? 1 : (nkt == 2 ? 2 : (nkt <= 4 ? 4 : (nkt <= 7 ? 7 : 11)))) * 32;
+        if (7 * np * p.hd * 2 + 2 * np * 4 + (size_t)2 * p.M3 * 4 + np * 8 + 16 > 160 * 1024) return false;
+    }
     return dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 352 && p.M3 <= 4095 && p.bws == p.ws && (C % 8) == 0 &&
            !getenv("MSSEG_ATTN_NO_MFMA") && !getenv("MSSEG_ATTN_BWD_NO_MFMA");
 }
