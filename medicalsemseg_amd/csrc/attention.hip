@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const AttnParams p) {
             regS[i] = rg;
             codeS[i] = cd;
         }
-        for (int h = 0; h < p.heads; ++h) {
+        for (int h = blockIdx.y; h < p.heads; h += gridDim.y) {
             __syncthreads();
             for (int i = threadIdx.x; i < p.M3; i += 256) tabS[i] = p.table[(long long)i * p.heads + h];
             for (int i = threadIdx.x; i < p.N * HD; i += 256) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(const AttnParams p) {
             regS[i] = rg;
             codeS[i] = cd;
         }
-        for (int h = 0; h < p.heads; ++h) {
+        for (int h = blockIdx.y; h < p.heads; h += gridDim.y) {
             __syncthreads();
             float* dtab = p.dtab_all_heads ? dtabS + h * p.M3 : dtabS;
             for (int i = threadIdx.x; i < p.M3; i += 256) tabS[i] = p.table[(long long)i * p.heads + h];
@@ -476,7 +476,10 @@ int fill_attn(AttnParams& p, int B, int S, int H, int W, int C, int heads, int w
 #define ATTN_LAUNCH(KERN, T_, SMEM)                                                                      \
     do {                                                                                                 \
         int gx__ = p.nwin_total < msseg_num_cus() * 2 ? p.nwin_total : msseg_num_cus() * 2;              \
-        dim3 grid(gx__, 1);                                                                              \
+        int gy__ = (msseg_num_cus() * 2 + gx__ - 1) / gx__;                                              \
+        if (gy__ > p.heads) gy__ = p.heads;                                                              \
+        if (p.dtab_all_heads) gy__ = 1;                                                                  \
+        dim3 grid(gx__, gy__);                                                                            \
         if (p.hd == 8) { if (int rc__ = attn_set_lds((const void*)KERN<T_, 8>, SMEM)) return rc__;          \
             hipLaunchKernelGGL((KERN<T_, 8>), grid, dim3(256), SMEM, (hipStream_t)stream, p); }              \
         else if (p.hd == 16) { if (int rc__ = attn_set_lds((const void*)KERN<T_, 16>, SMEM)) return rc__;   \
@@ -511,7 +514,7 @@ int msseg_window_attention_fwd2(const void* qkv, const float* qkv_bias, const fl
     p.qkv = qkv; p.qkv_bias = qkv_bias; p.table = table; p.out = out; p.lse = lse;
     const size_t smem = (size_t)p.N * p.hd * 2 * 4 + (size_t)p.M3 * 4 + (size_t)p.N * 3 * 4;
     if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd: window too large for LDS");
-    if (dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 352 && p.M3 <= 4095 && p.bws == p.ws && (C % 8) == 0 &&
+    if (dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 352 && p.M3 <= 4095 && (C % 8) == 0 &&
         !getenv("MSSEG_ATTN_NO_MFMA")) {
         // bf16: QK^T and PV on the matrix cores (attention_mfma.hip)
         return msseg_window_attention_fwd_mfma(p, (hipStream_t)stream);
@@ -529,7 +532,7 @@ static bool attn_bwd_on_mfma(const AttnParams& p, int C, int dtype) {
         const size_t np = (size_t)(nkt == 1 ? 1 : (nkt == 2 ? 2 : (nkt <= 4 ? 4 : (nkt <= 7 ? 7 : 11)))) * 32;
         if (7 * np * p.hd * 2 + 2 * np * 4 + (size_t)2 * p.M3 * 4 + np * 8 + 16 > 160 * 1024) return false;
     }
-    return dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 352 && p.M3 <= 4095 && p.bws == p.ws && (C % 8) == 0 &&
+    return dtype == MSSEG_BF16 && (p.hd == 16 || p.hd == 32) && p.N <= 352 && p.M3 <= 4095 && (C % 8) == 0 &&
            !getenv("MSSEG_ATTN_NO_MFMA") && !getenv("MSSEG_ATTN_BWD_NO_MFMA");
 }
 

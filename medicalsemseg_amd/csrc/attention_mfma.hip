@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const AttnParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int nW = p.nWs * p.nWh * p.nWw;
-    const int m = 2 * p.ws - 1;
-    const int off = ((p.ws - 1) * m + (p.ws - 1)) * m + (p.ws - 1);
+    const int m = 2 * p.bws - 1;
+    const int off = ((p.bws - 1) * m + (p.bws - 1)) * m + (p.bws - 1);
     const int C3 = 3 * p.C;
 
     for (int wb = blockIdx.x; wb < p.nwin_total; wb += gridDim.x) {
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const AttnParams
                 kinfo[i] = 0xFFFFFFFFu;
             }
         }
-        for (int h = 0; h < p.heads; ++h) {
+        for (int h = blockIdx.y; h < p.heads; h += gridDim.y) {   // heads split over grid.y when there are few windows
             __syncthreads();
             for (int i = tid; i < p.M3; i += 256) tabS[i] = p.table[(long long)i * p.heads + h];
             // stage Q, K (row-major) and V (transposed): one 16-byte chunk (8 channels) per thread-iteration
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int nW = p.nWs * p.nWh * p.nWw;
-    const int m = 2 * p.ws - 1;
-    const int off = ((p.ws - 1) * m + (p.ws - 1)) * m + (p.ws - 1);
+    const int m = 2 * p.bws - 1;
+    const int off = ((p.bws - 1) * m + (p.bws - 1)) * m + (p.bws - 1);
     const int C3 = 3 * p.C;
     const int vrow = r & (HD - 1);
 
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const AttnParams
                 kinfo[i] = 0xFFFFFFFFu;
             }
         }
-        for (int h = 0; h < p.heads; ++h) {
+        for (int h = blockIdx.y; h < p.heads; h += gridDim.y) {   // heads split over grid.y when there are few windows
             __syncthreads();
             for (int i = tid; i < p.M3; i += 256) { tabS[i] = p.table[(long long)i * p.heads + h]; dtabS[i] = 0.f; }
             bf16_t* dsw = DSWS ? (bf16_t*)p.ds_ws + ((long long)wb * p.heads + h) * (NKT * NKT * 1024) + lane * 16 : nullptr;
@@ -493,8 +493,8 @@ __global__ __launch_bounds__(256) void attn_dtable_gather_kernel(const float* __
     float v = 0.f;
     for (int qi = i; qi < N; qi += 256) {     // windows of up to 352 tokens: a thread may own two queries
         const int jz = qi / (wsz * wsz) - dz, jy = (qi / wsz) % wsz - dy, jx = qi % wsz - dx;
-        if (jz >= 0 && jz < wsz && jy >= 0 && jy < wsz && jx >= 0 && jx < wsz) {
-            const int j = (jz * wsz + jy) * wsz + jx;
+        const int j = (jz * wsz + jy) * wsz + jx;
+        if (jz >= 0 && jz < wsz && jy >= 0 && jy < wsz && jx >= 0 && jx < wsz && j < N) {
             // fragment order of the backward kernel's pass 1: tile (i / 32, j / 32), lane = (i % 32) + 32 * hh,
             // register g with key offset (g & 3) + 8 * (g >> 2) + 4 * hh
             const int kk = j & 31, hh = (kk >> 2) & 1, g = (kk & 3) + 4 * (kk >> 3);
@@ -527,7 +527,9 @@ template <int HD, int NKT> int launch_bwd(const AttnParams& p, hipStream_t strea
     }
     if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd_mfma: window too large for LDS (%zu bytes)", smem);
     int gx = p.nwin_total < msseg_num_cus() * 2 ? p.nwin_total : msseg_num_cus() * 2;
-    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), smem, stream, p);
+    int gy = (msseg_num_cus() * 2 + gx - 1) / gx;      // few windows (deep stages): spread the heads over workgroups too
+    if (gy > p.heads) gy = p.heads;
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), smem, stream, p);
     MSSEG_CHECK_LAUNCH("window_attention_bwd_mfma");
     if (dsws) {
         const int E = NKT * NKT * 1024;
@@ -537,7 +539,7 @@ template <int HD, int NKT> int launch_bwd(const AttnParams& p, hipStream_t strea
                            (const bf16_t*)p.ds_ws, p.ds_psum, p.nwin_total, p.heads, E, chunk);
         MSSEG_CHECK_LAUNCH("attn_ds_window_sum");
         hipLaunchKernelGGL(attn_dtable_gather_kernel, dim3(p.M3, p.heads), dim3(256), 0, stream, (const float*)p.ds_psum,
-                           p.dtable, groups, p.heads, NKT, p.ws, p.N);
+                           p.dtable, groups, p.heads, NKT, p.bws, p.N);
         MSSEG_CHECK_LAUNCH("attn_dtable_gather");
     }
     return MSSEG_OK;
@@ -566,7 +568,9 @@ template <int HD, int NKT> int launch(const AttnParams& p, hipStream_t stream) {
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((win_attn_fwd_mfma_kernel<HD, NKT>), dim3(gx), dim3(256), smem, stream, p);
+    int gy = (msseg_num_cus() * 4 + gx - 1) / gx;
+    if (gy > p.heads) gy = p.heads;
+    hipLaunchKernelGGL((win_attn_fwd_mfma_kernel<HD, NKT>), dim3(gx, gy), dim3(256), smem, stream, p);
     MSSEG_CHECK_LAUNCH("window_attention_fwd_mfma");
     return MSSEG_OK;
 }

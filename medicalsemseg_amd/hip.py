@@ -908,7 +908,7 @@ def window_attention_bwd(qkv, qkv_bias, table, out, lse, dout, dqkv, dtable, hea
     B, S, H, W, C3 = qkv.shape
     wsb = 0
     bws = bias_ws or ws
-    if dtable is not None and bws == ws:
+    if dtable is not None:
         wsb = int(lib().msseg_window_attention_bwd_workspace_bytes(B, S, H, W, C3 // 3, heads, ws, shift, dt(qkv)))
     work = torch.empty(wsb, dtype=torch.uint8, device=qkv.device) if wsb else None
     _ck(lib().msseg_window_attention_bwd2(_p(qkv), _p(qkv_bias), _p(table), _p(out), _p(lse), _p(dout), _p(dqkv),

@@ -253,8 +253,9 @@ def test_swin_official_net_vs_reference_golden_and_oracle(golden_dir, dtype):
         assert err < 0.08 and abs(float(loss.detach()) - float(loss_ref.detach())) < 3e-2 and tot < 0.15
 
 
-@pytest.mark.parametrize("R,ws,heads,C,shift", [(12, 7, 3, 48, 3), (14, 7, 4, 64, 0), (9, 7, 3, 48, 3)])
-def test_window7_attention_mfma_equals_vector_kernels(monkeypatch, R, ws, heads, C, shift):
+@pytest.mark.parametrize("R,ws,heads,C,shift,bws", [(12, 7, 3, 48, 3, 7), (14, 7, 4, 64, 0, 7), (9, 7, 3, 48, 3, 7),
+                                                       (6, 6, 24, 384, 0, 7), (4, 4, 12, 192, 0, 7)])
+def test_window7_attention_mfma_equals_vector_kernels(monkeypatch, R, ws, heads, C, shift, bws):
     """343-token windows (MONAI Swin-UNETR): the bf16 MFMA kernels (11 key tiles, online-softmax chunks, 12-bit bias
     codes) against the exact-fp32-math vector kernels on the same bf16 operands, forward and backward, with padding
     (12 -> 14, 9 -> 14) and the shift mask"""
@@ -262,7 +263,7 @@ def test_window7_attention_mfma_equals_vector_kernels(monkeypatch, R, ws, heads,
     torch.manual_seed(7)
     qkv = (torch.randn(2, R, R, R, 3 * C, device=DEV) * 0.7).bfloat16()
     qb = torch.randn(3 * C, device=DEV) * 0.3
-    tab = torch.randn((2 * ws - 1) ** 3, heads, device=DEV) * 0.3
+    tab = torch.randn((2 * bws - 1) ** 3, heads, device=DEV) * 0.3     # bws > ws: clamped window, sliced 7^3 index
     dout = torch.randn(2, R, R, R, C, device=DEV).bfloat16()
     res = []
     for no_mfma in (False, True):
@@ -271,10 +272,10 @@ def test_window7_attention_mfma_equals_vector_kernels(monkeypatch, R, ws, heads,
         else:
             monkeypatch.delenv("MSSEG_ATTN_NO_MFMA", raising=False)
         out = torch.empty(2, R, R, R, C, device=DEV, dtype=torch.bfloat16)
-        lse = hip.window_attention_fwd(qkv, qb, tab, out, heads, ws, shift)
+        lse = hip.window_attention_fwd(qkv, qb, tab, out, heads, ws, shift, bws)
         dqkv = torch.empty_like(qkv)
         dtab = torch.zeros_like(tab)
-        hip.window_attention_bwd(qkv, qb, tab, out, lse, dout, dqkv, dtab, heads, ws, shift)
+        hip.window_attention_bwd(qkv, qb, tab, out, lse, dout, dqkv, dtab, heads, ws, shift, bws)
         res.append((out.float(), lse.clone(), dqkv.float(), dtab.clone()))
     monkeypatch.delenv("MSSEG_ATTN_NO_MFMA", raising=False)
     (o0, l0, d0, t0), (o1, l1, d1, t1) = res
