@@ -105,8 +105,9 @@ class _GraphedInfer:
     """`seg = predictor.infer_cl(win)` on a static batch of channels-last windows, replayed from a captured hipGraph
     (models that declare `graph_safe` -- static shapes, no host synchronisation -- and offer `infer_cl`: channels-last
     in, channels-last logits out, no layout passes, nothing retained).  A window batch is ~70 launches of 20-500 us;
-    issued from Python the small ones are launch-bound.  The captured graph starts with the batched weight
-    re-packing, so a replay always sees the current parameters."""
+    issued from Python the small ones are launch-bound.  The packed weight images are NOT rebuilt inside the graph (an
+    inference loop replays it hundreds of times on unchanged weights): `sliding_window_inference` checks them once per
+    call, eagerly (`layers.PACK_REGISTRY.refresh_if_stale`)."""
 
     _cache = {}
 
@@ -129,7 +130,7 @@ class _GraphedInfer:
             predictor.infer_cl(self.win)    # warm-up: packed-weight images, workspaces
         torch.cuda.current_stream().wait_stream(side)
         layers.PACK_REGISTRY.prepare()
-        layers.bump_weights_epoch()   # the capture then starts with the batched weight re-packing
+        layers.PACK_REGISTRY.refresh_if_stale(dev)    # images are current: the capture contains no repack
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.seg = predictor.infer_cl(self.win)
@@ -195,6 +196,8 @@ def sliding_window_inference(inputs: torch.Tensor, affine, roi_size, sw_batch_si
         # gather -> graph replay of the forward -> [all-gather] -> blend, per step; the accumulators are updated step by
         # step (memory O(volume), as the reference), windows and logits never leave the channels-last compute dtype
         g = _GraphedInfer.get(predictor, nb, Cin, roi, dev)
+        from .. import layers
+        layers.PACK_REGISTRY.refresh_if_stale(dev)    # parameters may have changed since the graph was captured
         out, cnt = accumulators(predictor.out_channels)
         for i in range(nsteps):
             g0 = (i * ws + rk) * nb                       # this rank's batch of the step (all slots unused: idle replay)

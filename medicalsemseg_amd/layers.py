@@ -66,6 +66,15 @@ class _PackRegistry:
             if g["jobs"]:
                 self._ensure_table(g, device)
 
+    def refresh_if_stale(self, device=None):
+        """eager check for callers that replay graphs captured WITHOUT the repack (inference): one batched repack per
+        stale (device, dtype) group, nothing when the parameters did not change"""
+        for (dev, dtype), g in self.groups.items():
+            if device is not None and dev != device:
+                continue
+            if any(r["state"] != (r["src"]._version, weights_epoch) for r in g["jobs"]):
+                self.refresh(dev, dtype)
+
     def refresh(self, device, dtype):
         g = self.groups[(device, dtype)]
         jobs = g["jobs"]
