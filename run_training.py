@@ -46,7 +46,22 @@ def main(cfg):
                          "reference (data/*) is outside the hot-path scope (SURVEY.md section 2)")
     vol = cfg.vol_size if isinstance(cfg.vol_size, int) else cfg.vol_size[0]
     vval = cfg.synthetic_val_size if isinstance(cfg.synthetic_val_size, int) else cfg.synthetic_val_size[0]
-    loader_train = SyntheticLoader(cfg.synthetic_steps, cfg.n_images_per_batch, vol, cfg.in_chans, cfg.output_dim, seed)
+    if cfg.t_rand_crop_fgbg:
+        # device-side data path: one synthetic "CT" of 2x the patch size cached in HBM, patches cropped
+        # (fg / bg centres with the reference's pos : neg odds) and augmented by one gather kernel per batch
+        from medicalsemseg_amd.data import sphere_labels
+        from medicalsemseg_amd.data_device import DevicePatchLoader
+        g = torch.Generator().manual_seed(seed)
+        lab = sphere_labels(2 * vol, cfg.output_dim)
+        img = torch.randn(cfg.in_chans, 2 * vol, 2 * vol, 2 * vol, generator=g) + 0.5 * lab[None]
+        loader_train = DevicePatchLoader(img, lab, vol, cfg.n_images_per_batch, cfg.synthetic_steps, device, seed=seed,
+                                         pos=cfg.t_rand_crop_pos_weight or 1.0, neg=cfg.t_rand_crop_neg_weight or 1.0,
+                                         flip_prob=cfg.t_flip_prob, rot_prob=cfg.t_rot_prob,
+                                         shift_os=cfg.t_intensity_shift_os, shift_prob=cfg.t_intensity_shift_prob,
+                                         scale_f=cfg.t_intensity_scale_factors, scale_prob=cfg.t_intensity_scale_prob,
+                                         image_threshold=-1e9)
+    else:
+        loader_train = SyntheticLoader(cfg.synthetic_steps, cfg.n_images_per_batch, vol, cfg.in_chans, cfg.output_dim, seed)
     loader_val = SyntheticLoader(1, 1, vval, cfg.in_chans, cfg.output_dim, seed + 7, with_crop_info=False)
 
     model = build_model(cfg).to(device)

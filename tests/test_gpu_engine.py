@@ -144,6 +144,18 @@ def test_run_training_driver_synthetic(tmp_path):
     assert "conv_0.conv_0.conv.weight" in ck["model"] and ck["epoch"] == 1
 
 
+def test_run_training_driver_device_data_path(tmp_path):
+    """the driver fed by the device-side crop + augmentation loader (N1): fg/bg crops, flips, rot90, intensity jitter"""
+    cmd = [sys.executable, os.path.join(ROOT, "run_training.py"), "--synthetic", "--model", "UNetSmall", "--output_dim", "3",
+           "--vol_size", "32", "--n_images_per_batch", "2", "--synthetic_steps", "4", "--epochs", "2", "--val_interval", "2",
+           "--synthetic_val_size", "48", "--warmup_epochs", "1", "--output_dir", str(tmp_path), "--save_ckpt_freq", "2",
+           "--t_rand_crop_fgbg", "--t_flip_prob", "0.5", "--t_rot_prob", "0.5", "--t_intensity_shift_prob", "0.5",
+           "--t_intensity_scale_prob", "0.5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(tmp_path / "checkpoint-1.pth")
+
+
 def test_run_training_two_ranks_share_one_gpu_over_gloo(tmp_path):
     """data-parallel control flow of the driver (weight broadcast, GradSync with the two-phase backward, meter and
     loss reductions, rank-0 checkpointing) with two gloo ranks on this one GPU; RCCL needs one GPU per rank"""
