@@ -261,6 +261,12 @@ int msseg_channel_sum(const void* x, long long ldx, float* out, long long rows, 
 /* y = a + b (elementwise over rows x C with strides) */
 int msseg_add(const void* a, long long lda, const void* b, long long ldb, void* y, long long ldy, long long rows,
               int C, int dtype, msseg_stream_t stream);
+/* y[n] = a[n] + scale[n] * b[n] over N samples of elems_per_sample dense elements (a NULL: y = scale * b; scale NULL: 1):
+ * residual add with the per-sample stochastic-depth factor mask[n] / keep folded in (models/layers/drop_path.py:15-45,
+ * swin_nnformer.py:286-287) and the branch gradient of its backward. */
+int msseg_axpy_rows(const void* a, const void* b, const float* scale, void* y, int N, long long elems_per_sample, int dtype,
+                    msseg_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * Swin transformer pieces (models/backbones/swin_nnformer.py).  Linear layers are msseg_conv3d_k1_* on tokens.

@@ -1007,6 +1007,25 @@ __global__ void add_kernel(const T* a, long long lda, const T* b, long long ldb,
     }
 }
 
+// y[n][r][:] = a[n][r][:] + s[n] * b[n][r][:]   (a nullable: y = s * b; s nullable: s = 1) -- the residual add of the Swin
+// blocks with the per-sample stochastic-depth scale mask[n] / keep folded in (models/layers/drop_path.py:15-45), and its
+// backward (branch gradient = s[n] * dy).  16-byte chunks, rows_per_sample rows per sample.
+template <typename T>
+__global__ __launch_bounds__(256) void axpy_rows_vec_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                            const float* __restrict__ s, T* __restrict__ y,
+                                                            long long chunks_per_sample, long long total_chunks) {
+    constexpr int EPC = DT<T>::EPC;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total_chunks; i += (long long)gridDim.x * 256) {
+        const float sc = s ? s[i / chunks_per_sample] : 1.f;
+        Chunk<T> cb, ca, o;
+        cb.load(b + i * EPC);
+        if (a) ca.load(a + i * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.v[e] = (a ? ca.v[e] : 0.f) + sc * cb.v[e];
+        o.store(y + i * EPC);
+    }
+}
+
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict__ dst, int M, int M0, int Tt, int K,
                                     int K0, long long s_m1, long long s_m0, long long s_t, long long s_k1,
@@ -1588,6 +1607,24 @@ int msseg_add(const void* a, long long lda, const void* b, long long ldb, void* 
                hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
                                   (const bf16_t*)b, ldb, (bf16_t*)y, ldy, rows, C));
     MSSEG_CHECK_LAUNCH("add");
+    return MSSEG_OK;
+}
+
+int msseg_axpy_rows(const void* a, const void* b, const float* scale, void* y, int N, long long elems_per_sample, int dtype,
+                    msseg_stream_t stream) {
+    if (!b || !y || N < 1 || elems_per_sample < 1) MSSEG_FAIL(MSSEG_EINVAL, "axpy_rows: bad args");
+    const int esz = dtype == MSSEG_F32 ? 4 : 2, epc = 16 / esz;
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "axpy_rows: bad dtype");
+    if ((elems_per_sample % epc) || ((uintptr_t)b & 15) || ((uintptr_t)y & 15) || (a && ((uintptr_t)a & 15)))
+        MSSEG_FAIL(MSSEG_EINVAL, "axpy_rows: dense 16-byte aligned tensors with elems_per_sample %% %d == 0 expected", epc);
+    const long long cps = elems_per_sample / epc, total = cps * N;
+    const int g = grid_for(total, 2);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(axpy_rows_vec_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)a,
+                                  (const float*)b, scale, (float*)y, cps, total),
+               hipLaunchKernelGGL(axpy_rows_vec_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+                                  (const bf16_t*)b, scale, (bf16_t*)y, cps, total));
+    MSSEG_CHECK_LAUNCH("axpy_rows");
     return MSSEG_OK;
 }
 

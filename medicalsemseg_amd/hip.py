@@ -88,6 +88,7 @@ SIGNATURES = {
     "msseg_ncdhw_to_ndhwc": ([_vp, _i, _vp, _ll, _i, _i, _i, _ll, _vp], _i),
     "msseg_ndhwc_to_ncdhw": ([_vp, _ll, _i, _vp, _i, _i, _i, _ll, _vp], _i),
     "msseg_channel_sum": ([_vp, _ll, _vp, _ll, _i, _i, _vp, _sz, _i, _vp], _i),
+    "msseg_axpy_rows": ([_vp, _vp, _vp, _vp, _i, _ll, _i, _vp], _i),
     "msseg_add": ([_vp, _ll, _vp, _ll, _vp, _ll, _ll, _i, _i, _vp], _i),
     "msseg_dice_ce_partials": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _i, _ll, _i, _vp], _i),
     "msseg_dice_ce_fwd": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _vp, _i, _ll, _i, _f, _f, _vp, _sz, _vp], _i),
@@ -692,6 +693,15 @@ def channel_sum(x, out, accumulate=False):
     _ck(lib().msseg_channel_sum(_p(x), ld(x), _p(out), rows, Cc, int(accumulate), _p(sc), sc.numel(), dt(x),
                                 _stream()), "channel_sum")
     return out
+
+
+def axpy_rows(a, b, scale, y):
+    """y[n] = a[n] + scale[n] * b[n] (a None: scale * b; scale None: plain add) on dense tensors [N, ...]"""
+    _need_gpu(b, y)
+    assert b.is_contiguous() and y.is_contiguous() and (a is None or a.is_contiguous())
+    N = b.shape[0]
+    _ck(lib().msseg_axpy_rows(_p(a), _p(b), _p(scale), _p(y), N, b.numel() // N, dt(b), _stream()), "axpy_rows")
+    return y
 
 
 def add(a, b, y):

@@ -63,12 +63,16 @@ class _Block(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio))
 
-    def _dp(self, x):
+    def _dp_scale(self, x):
+        """per-sample stochastic-depth factor mask[b] / keep (models/layers/drop_path.py:15-45), or None; the multiply
+        happens inside the residual-add kernel.  `self.dp_mask` (fp32 [B] of 0 / 1) overrides the draw (tests)."""
         if self.drop_path == 0.0 or not self.training:
-            return x
-        keep = 1.0 - self.drop_path   # per-sample stochastic depth (models/layers/drop_path.py:15-45)
-        mask = torch.empty(x.shape[0], 1, 1, 1, 1, device=x.device, dtype=torch.float32).bernoulli_(keep) / keep
-        return x * mask.to(x.dtype)
+            return None
+        keep = 1.0 - self.drop_path
+        mask = getattr(self, "dp_mask", None)
+        if mask is None:
+            mask = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
+        return mask.to(device=x.device, dtype=torch.float32) / keep
 
     def forward(self, x):
         a = self.attn
@@ -76,11 +80,11 @@ class _Block(nn.Module):
         qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias)
         y = ops.WindowAttnFn.apply(qkv, a.qkv.bias, a.relative_position_bias_table, self.heads, self.ws, self.shift)
         y = ops.linear(y, a.proj.weight, a.proj.bias)
-        x = ops.add(x, self._dp(y))
+        x = ops.add(x, y, self._dp_scale(x))
         y = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         y = ops.gelu(ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
         y = ops.linear(y, self.mlp.fc2.weight, self.mlp.fc2.bias)
-        return ops.add(x, self._dp(y))
+        return ops.add(x, y, self._dp_scale(x))
 
 
 class _PatchMerging(nn.Module):

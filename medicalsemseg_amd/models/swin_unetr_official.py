@@ -180,6 +180,32 @@ class SwinUNETR(nn.Module):
         self._build_ops()
         return r
 
+    def load_from(self, weights):
+        """copy a self-supervised MONAI Swin-ViT checkpoint into the encoder (swin_unetr_official.py:232-280 and the
+        per-block mapper :617-649): keys ``module.patch_embed.proj.*``, ``module.layers{1..4}.0.blocks.{n}.*``,
+        ``module.layers{1..4}.0.downsample.{reduction,norm}.*`` of ``weights["state_dict"]``"""
+        sd = weights["state_dict"]
+        block_names = ["norm1.weight", "norm1.bias", "attn.relative_position_bias_table", "attn.relative_position_index",
+                       "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight",
+                       "norm2.bias", "mlp.linear1.weight", "mlp.linear1.bias", "mlp.linear2.weight", "mlp.linear2.bias"]
+        src_names = dict(zip(block_names, block_names))
+        src_names.update({"mlp.linear1.weight": "mlp.fc1.weight", "mlp.linear1.bias": "mlp.fc1.bias",
+                          "mlp.linear2.weight": "mlp.fc2.weight", "mlp.linear2.bias": "mlp.fc2.bias"})
+        own = dict(self.swinViT.named_parameters())
+        own.update(dict(self.swinViT.named_buffers()))
+        with torch.no_grad():
+            own["patch_embed.proj.weight"].copy_(sd["module.patch_embed.proj.weight"])
+            own["patch_embed.proj.bias"].copy_(sd["module.patch_embed.proj.bias"])
+            for li in range(1, 5):
+                layer = getattr(self.swinViT, f"layers{li}")[0]
+                for bname, _ in layer.blocks.named_children():
+                    for n in block_names:
+                        own[f"layers{li}.0.blocks.{bname}.{n}"].copy_(sd[f"module.layers{li}.0.blocks.{bname}.{src_names[n]}"])
+                for n in ("reduction.weight", "norm.weight", "norm.bias"):
+                    own[f"layers{li}.0.downsample.{n}"].copy_(sd[f"module.layers{li}.0.downsample.{n}"])
+        from .. import layers as _layers
+        _layers.bump_weights_epoch()      # packed weight images are rebuilt on the next forward
+
     def forward(self, x_in):
         vol = x_in[0] if isinstance(x_in, (tuple, list)) else x_in
         if not vol.is_cuda:

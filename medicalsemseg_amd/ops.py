@@ -106,14 +106,26 @@ class GeluFn(torch.autograd.Function):
 
 
 class AddFn(torch.autograd.Function):
+    """a + scale[n] * b: the residual add of a Swin block; `scale` (fp32 [B] or None) is the stochastic-depth factor
+    mask[n] / keep of /root/reference/models/layers/drop_path.py:15-45, folded into the add (one kernel, no product tensor)"""
+
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, scale=None):
         a, b = _c(a), _c(b)
+        ctx.scale = scale
+        epc = 16 // a.element_size()
+        if (a.numel() // a.shape[0]) % epc == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0:
+            return hip.axpy_rows(a, b, scale, torch.empty_like(a))
+        if scale is not None:
+            raise ValueError("stochastic depth needs 16-byte aligned dense activations")
         return hip.add(a, b, torch.empty_like(a))
 
     @staticmethod
     def backward(ctx, dy):
-        return dy, dy
+        if ctx.scale is None:
+            return dy, dy, None
+        dy = _c(dy)
+        return dy, hip.axpy_rows(None, dy, ctx.scale, torch.empty_like(dy)), None
 
 
 class WindowAttnFn(torch.autograd.Function):
@@ -247,5 +259,5 @@ def gelu(x):
     return GeluFn.apply(x)
 
 
-def add(a, b):
-    return AddFn.apply(a, b)
+def add(a, b, scale=None):
+    return AddFn.apply(a, b, scale)

@@ -251,3 +251,47 @@ def test_overlapped_gradient_exchange_equals_plain_exchange_two_ranks():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DP_OVERLAP_OK" in r.stdout
+
+
+def test_resume_from_reference_layout_checkpoint(tmp_path):
+    """a checkpoint written the way the reference writes it (/root/reference/utils/misc.py:268-283: torch.optim.AdamW
+    state dict over timm's two parameter groups, `cfg` stored as an argparse.Namespace) resumes into FlatAdamW: weights,
+    both moments in param-group order, step count and epoch"""
+    import argparse
+    from medicalsemseg_amd.models.unet import UNET_FEATURES, UNet
+    from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay
+    from medicalsemseg_amd.utils import misc
+    from oracle.blocks import BasicUNet
+    torch.manual_seed(1)
+    ref = BasicUNet(1, 2, UNET_FEATURES["UNetSmall"])
+    topt = torch.optim.AdamW(add_weight_decay(ref, 1e-5), lr=1e-3, betas=(0.9, 0.95), eps=1e-6)
+    for _ in range(2):
+        ref(torch.randn(1, 1, 16, 16, 16)).square().mean().backward()
+        topt.step()
+        topt.zero_grad()
+    path = str(tmp_path / "ref_ckpt.pth")
+    torch.save({"model": ref.state_dict(), "optimizer": topt.state_dict(), "epoch": 4, "scaler": None, "scheduler": None,
+                "cfg": argparse.Namespace(model="UNetSmall", lr=1e-3)}, path)
+    net = UNet(1, 2, UNET_FEATURES["UNetSmall"], compute_dtype=torch.float32).to(DEV)
+    opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=1e-3, betas=(0.9, 0.95), eps=1e-6)
+    cfg = argparse.Namespace(resume=path, start_epoch=0, eval=False)
+    misc.load_model(cfg, net, opt)
+    assert cfg.start_epoch == 5 and opt._step == 2
+    ref_params = [p for g in topt.param_groups for p in g["params"]]
+    off = 0
+    for (p, _), rp in zip(opt._views, ref_params):
+        k = p.numel()
+        assert torch.equal(p.detach().cpu(), rp.detach())
+        st = topt.state[rp]
+        assert torch.equal(opt.exp_avg[off:off + k].cpu(), st["exp_avg"].reshape(-1))
+        assert torch.equal(opt.exp_avg_sq[off:off + k].cpu(), st["exp_avg_sq"].reshape(-1))
+        off += k
+    # one more step on both sides stays in agreement (bias correction uses the restored step count)
+    x = torch.randn(1, 1, 16, 16, 16)
+    ref(x).square().mean().backward()
+    topt.step()
+    net((x.to(DEV), None, None)).float().square().mean().backward()
+    opt.step()
+    num = sum(float(((p.detach().cpu() - rp.detach()) ** 2).sum()) for (p, _), rp in zip(opt._views, ref_params))
+    den = sum(float((rp.detach() ** 2).sum()) for rp in ref_params)
+    assert (num / den) ** 0.5 < 1e-4

@@ -283,3 +283,44 @@ def test_window7_attention_mfma_equals_vector_kernels(monkeypatch, R, ws, heads,
     assert float((l0 - l1).abs().max()) < 2e-2
     assert float((d0 - d1).norm() / d1.norm()) < 3e-2
     assert float((t0 - t1).norm() / t1.norm()) < 3e-2
+
+
+def test_drop_path_residual_add_vs_reference_golden(golden_dir):
+    """stochastic depth folded into the residual-add kernel: with the reference's own mask (recovered from the
+    DropPath(0.2) golden of /root/reference/models/layers/drop_path.py under seed 7), shortcut + drop_path(branch)
+    equals the reference's arithmetic, forward and backward; eval mode is the plain add"""
+    from medicalsemseg_amd import ops
+    g = _load(golden_dir, "layers_ref.npz")
+    x, y_ref = torch.from_numpy(g["dp_x"]), torch.from_numpy(g["dp_y"])            # [16, 5, 7]
+    kept = (y_ref.abs().reshape(16, -1).max(1).values > 0).float()
+    assert 0 < float(kept.sum()) < 16
+    B = 16
+    branch = torch.zeros(B, 2, 2, 2, 40)
+    branch.reshape(B, -1)[:, :35] = x.reshape(B, -1)
+    shortcut = det_tensor("dp_short", (B, 2, 2, 2, 40))
+    for dtype in (torch.float32, torch.bfloat16):
+        a = shortcut.to(DEV, dtype).requires_grad_(True)
+        b = branch.to(DEV, dtype).requires_grad_(True)
+        out = ops.add(a, b, (kept / 0.8).to(DEV))
+        want = shortcut.to(dtype).float() + torch.zeros_like(branch).copy_(branch.to(dtype).float())* (kept / 0.8).view(B, 1, 1, 1, 1)
+        tol = 1e-6 if dtype == torch.float32 else 1e-2
+        assert float((out.float().cpu() - want).abs().max()) < tol
+        if dtype == torch.float32:   # the golden itself: branch part of the sum == reference DropPath output
+            got_dp = (out.float().cpu() - shortcut).reshape(B, -1)[:, :35].reshape(16, 5, 7)
+            assert float((got_dp - y_ref).abs().max()) < 1e-5
+        r = det_tensor("dp_r", tuple(out.shape)).to(DEV, dtype)
+        (out * r).sum().backward()
+        assert torch.equal(a.grad, r)
+        assert float((b.grad.float().cpu() - r.float().cpu() * (kept / 0.8).view(B, 1, 1, 1, 1)).abs().max()) < tol
+    # a training-mode block draws its own mask; eval mode applies none
+    from medicalsemseg_amd.models.swin_unetr import _Block
+    blk = _Block(48, (6, 6, 6), 3, 6, 0, 4.0, True, 0.5).to(DEV)
+    xin = torch.randn(4, 6, 6, 6, 48, device=DEV)
+    blk.eval()
+    e1, e2 = blk(xin), blk(xin)
+    assert torch.equal(e1, e2)
+    blk.train()
+    blk.dp_mask = torch.tensor([1.0, 0.0, 1.0, 0.0])
+    t = blk(xin)
+    assert torch.equal(t[1], xin[1]) and torch.equal(t[3], xin[3])      # dropped samples keep the shortcut only
+    assert not torch.equal(t[0], e1[0])                                 # kept samples: branch scaled by 1 / keep

@@ -215,3 +215,29 @@ def test_window_sharding_is_a_partition():
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_swin_unetr_official_load_from_maps_pretrained_keys():
+    """SwinUNETR.load_from: the reference's pretrained-weight mapper (swin_unetr_official.py:232-280, :617-649), incl. the
+    checkpoint's mlp.fc1 / fc2 -> linear1 / linear2 renaming"""
+    import torch
+    from medicalsemseg_amd.models.swin_unetr_official import SwinUNETR
+    net = SwinUNETR((64, 64, 64), 1, 3, feature_size=12)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for name, t in list(net.swinViT.named_parameters()) + list(net.swinViT.named_buffers()):
+        src = "module." + name.replace("mlp.linear1", "mlp.fc1").replace("mlp.linear2", "mlp.fc2")
+        sd[src] = (torch.randn(t.shape, generator=g) if t.is_floating_point() else t.clone())
+    before_dec = net.decoder3.conv_block.conv1.conv.weight.clone()
+    net.load_from({"state_dict": sd})
+    assert torch.equal(net.swinViT.layers3[0].blocks[1].mlp.linear2.weight, sd["module.layers3.0.blocks.1.mlp.fc2.weight"])
+    assert torch.equal(net.swinViT.layers1[0].downsample.reduction.weight, sd["module.layers1.0.downsample.reduction.weight"])
+    assert torch.equal(net.swinViT.patch_embed.proj.bias, sd["module.patch_embed.proj.bias"])
+    assert torch.equal(net.swinViT.layers4[0].blocks[0].attn.relative_position_bias_table,
+                       sd["module.layers4.0.blocks.0.attn.relative_position_bias_table"])
+    assert torch.equal(net.decoder3.conv_block.conv1.conv.weight, before_dec)      # the conv decoder is untouched
+    cfg_ok = __import__("medicalsemseg_amd.models.model_builder", fromlist=["build_model"])
+    from medicalsemseg_amd.utils.arguments import get_args
+    cfg = get_args("--model SwinUNETR --vol_size 64 --hidden_dim 24 --output_dim 3".split())
+    m = cfg_ok.build_model(cfg)
+    assert type(m).__name__ == "SwinUNETR" and m.swinViT.layers1[0].blocks[0].attn.qkv.weight.shape == (72, 24)
