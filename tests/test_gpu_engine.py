@@ -144,6 +144,28 @@ def test_run_training_driver_synthetic(tmp_path):
     assert "conv_0.conv_0.conv.weight" in ck["model"] and ck["epoch"] == 1
 
 
+def test_run_evaluation_and_run_test_drivers(tmp_path):
+    """train -> checkpoint -> run_evaluation.py (eval_model, metrics json) and run_test.py (test_model, saved label maps)"""
+    base = ["--synthetic", "--model", "UNetSmall", "--output_dim", "2", "--vol_size", "32", "--synthetic_val_size", "48",
+            "--output_dir", str(tmp_path)]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_training.py"), *base, "--n_images_per_batch", "2",
+                        "--synthetic_steps", "3", "--epochs", "1", "--val_interval", "1", "--warmup_epochs", "1",
+                        "--save_ckpt_freq", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ck = str(tmp_path / "checkpoint-0.pth")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_evaluation.py"), *base, "--resume", ck, "--synthetic_steps", "2",
+                        "--batch_size_val", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import json
+    ev = json.load(open(tmp_path / "eval.json"))
+    assert set(ev) >= {"eval/loss", "eval/mDice"} and np.isfinite(ev["eval/loss"])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_test.py"), *base, "--resume", ck, "--synthetic_steps", "2",
+                        "--save_eval_output"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    pred = np.load(tmp_path / "test_output" / "Fold0" / "pred" / "synthetic_0_0.npy")
+    assert pred.dtype == np.uint8 and pred.shape == (48, 48, 48)
+
+
 def test_run_training_driver_device_data_path(tmp_path):
     """the driver fed by the device-side crop + augmentation loader (N1): fg/bg crops, flips, rot90, intensity jitter"""
     cmd = [sys.executable, os.path.join(ROOT, "run_training.py"), "--synthetic", "--model", "UNetSmall", "--output_dim", "3",
