@@ -149,10 +149,10 @@ def test_run_evaluation_and_run_test_drivers(tmp_path):
     base = ["--synthetic", "--model", "UNetSmall", "--output_dim", "2", "--vol_size", "32", "--synthetic_val_size", "48",
             "--output_dir", str(tmp_path)]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "run_training.py"), *base, "--n_images_per_batch", "2",
-                        "--synthetic_steps", "3", "--epochs", "1", "--val_interval", "1", "--warmup_epochs", "1",
-                        "--save_ckpt_freq", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--synthetic_steps", "3", "--epochs", "2", "--val_interval", "2", "--warmup_epochs", "1",
+                        "--save_ckpt_freq", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    ck = str(tmp_path / "checkpoint-0.pth")
+    ck = str(tmp_path / "checkpoint-1.pth")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "run_evaluation.py"), *base, "--resume", ck, "--synthetic_steps", "2",
                         "--batch_size_val", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
