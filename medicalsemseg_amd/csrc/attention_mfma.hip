@@ -519,12 +519,9 @@ template <int HD, int NKT> int launch_bwd(const AttnParams& p, hipStream_t strea
     const size_t smem = (size_t)7 * NP * HD * 2 + (size_t)2 * NP * 4 + (size_t)2 * p.M3 * 4 + (size_t)NP * 4 + (size_t)NP * 4 + 16;
     const bool dsws = p.ds_ws != nullptr && p.dtable != nullptr;
     auto kern = dsws ? win_attn_bwd_mfma_kernel<HD, NKT, true> : win_attn_bwd_mfma_kernel<HD, NKT, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[dsws]) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            MSSEG_FAIL(MSSEG_ELAUNCH, "window_attention_bwd_mfma: cannot set dynamic LDS size");
-        attr_set[dsws] = true;
-    }
+    static msseg_lds_attr_once attr[2];
+    if (!attr[dsws].ensure((const void*)kern, 160 * 1024))
+        MSSEG_FAIL(MSSEG_ELAUNCH, "window_attention_bwd_mfma: cannot set dynamic LDS size");
     if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_bwd_mfma: window too large for LDS (%zu bytes)", smem);
     int gx = p.nwin_total < msseg_num_cus() * 2 ? p.nwin_total : msseg_num_cus() * 2;
     int gy = (msseg_num_cus() * 2 + gx - 1) / gx;      // few windows (deep stages): spread the heads over workgroups too
@@ -560,13 +557,9 @@ template <int HD, int NKT> int launch(const AttnParams& p, hipStream_t stream) {
     int gx = p.nwin_total < msseg_num_cus() * 4 ? p.nwin_total : msseg_num_cus() * 4;
     if (smem > 160 * 1024) MSSEG_FAIL(MSSEG_EINVAL, "window_attention_fwd_mfma: window too large for LDS (%zu bytes)", smem);
     if (smem > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)win_attn_fwd_mfma_kernel<HD, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
-                MSSEG_FAIL(MSSEG_ELAUNCH, "window_attention_fwd_mfma: cannot set dynamic LDS size");
-            attr_set = true;
-        }
+        static msseg_lds_attr_once attr;
+        if (!attr.ensure((const void*)win_attn_fwd_mfma_kernel<HD, NKT>, 160 * 1024))
+            MSSEG_FAIL(MSSEG_ELAUNCH, "window_attention_fwd_mfma: cannot set dynamic LDS size");
     }
     int gy = (msseg_num_cus() * 4 + gx - 1) / gx;
     if (gy > p.heads) gy = p.heads;

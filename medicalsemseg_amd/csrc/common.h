@@ -28,6 +28,24 @@ void msseg_set_error(const char* fmt, ...);
         if (e__ != hipSuccess) MSSEG_FAIL(MSSEG_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)
 
+// ---- dynamic LDS above 64 KB ---------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a (kernel, device) pair.  One of these lives as a
+// function-local static next to each kernel instantiation: a bit per device ordinal, set after the first successful
+// call on that device; two threads racing on the first call both make the same (idempotent) setting.
+#include <atomic>
+struct msseg_lds_attr_once {
+    std::atomic<unsigned long long> done{0};
+    bool ensure(const void* kern, int bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        const bool tracked = dev >= 0 && dev < 64;
+        if (tracked && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return true;
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+        if (tracked) done.fetch_or(1ull << dev, std::memory_order_release);
+        return true;
+    }
+};
+
 // ---- per-dtype traits -------------------------------------------------------------
 // A "chunk" is 16 bytes of consecutive channels: 8 bf16 or 4 f32.  One MFMA k-group
 // (4 lane-quarters x 1 chunk) therefore spans CB = 4*EPC channels: 32 (bf16) / 16 (f32).

@@ -336,12 +336,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
 template <int STATS, int TIMING> int launch(const K3ppParams& p, hipStream_t stream) {
     const int lds = W_BYTES + 2 * HALO_BYTES + (STATS ? STAT_FLOATS * 4 : 0);
     auto kern = k3pp_kernel<STATS, TIMING>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            MSSEG_FAIL(MSSEG_ELAUNCH, "conv3d_k3_pp: cannot set dynamic LDS size %d", lds);
-        attr_set = true;
-    }
+    static msseg_lds_attr_once attr;
+    if (!attr.ensure((const void*)kern, lds)) MSSEG_FAIL(MSSEG_ELAUNCH, "conv3d_k3_pp: cannot set dynamic LDS size %d", lds);
     const int ncb = p.M / 32;
     const int tiles = p.N * ceil_div(p.D, TD) * ceil_div(p.H, TH) * ceil_div(p.W, TW);
     int gx = msseg_num_cus() / ncb;

@@ -312,13 +312,9 @@ int msseg_k3wg_pp_launch(const K3WgParams& p, int gx, hipStream_t stream) {
     K3WgParams pl = p;
     pl.dbg_noload = noload ? 1 : 0;
     const int lds = 2 * GRP_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k3wg_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k3wg_pp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            MSSEG_FAIL(MSSEG_ELAUNCH, "conv3d_k3_wgrad_pp: cannot set dynamic LDS size %d", lds);
-        attr_set = true;
-    }
+    static msseg_lds_attr_once attr[2];
+    if (!attr[0].ensure((const void*)k3wg_pp_kernel<0>, lds) || !attr[1].ensure((const void*)k3wg_pp_kernel<1>, lds))
+        MSSEG_FAIL(MSSEG_ELAUNCH, "conv3d_k3_wgrad_pp: cannot set dynamic LDS size %d", lds);
     const int pairs = ceil_div(p.M, 32) * ceil_div(p.K, 32);
     if (timing) hipLaunchKernelGGL(k3wg_pp_kernel<1>, dim3(gx, pairs, 1), dim3(NTHREADS), lds, stream, pl);
     else hipLaunchKernelGGL(k3wg_pp_kernel<0>, dim3(gx, pairs, 1), dim3(NTHREADS), lds, stream, pl);

@@ -700,13 +700,8 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
         p.rel32_ok = ((long long)(C::PD + 1) * xh * xw * p.ldx < 0x7fffffffLL) ? 1 : 0;
     }
     auto kern = igemm_fwd_kernel<T, NTAPS, SRC, EPI, TD, TH, TW, WAVES, NT, STRIDE, NSL, DIAG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) !=
-            hipSuccess)
-            MSSEG_FAIL(MSSEG_ELAUNCH, "igemm: cannot set dynamic LDS size %d", C::LDS_BYTES);
-        attr_set = true;
-    }
+    static msseg_lds_attr_once attr;
+    if (!attr.ensure((const void*)kern, C::LDS_BYTES)) MSSEG_FAIL(MSSEG_ELAUNCH, "igemm: cannot set dynamic LDS size %d", C::LDS_BYTES);
     const int ncb = ceil_div(p.M, C::COUTB);
     const int wg_per_cu = (C::LDS_BYTES > 80 * 1024) ? 1 : ((C::LDS_BYTES > 40 * 1024) ? 2 : 4);
     int gx = msseg_num_cus() * wg_per_cu / (ncb > 1 ? 1 : 1);

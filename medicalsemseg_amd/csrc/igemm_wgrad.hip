@@ -481,12 +481,8 @@ int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes
     if (gx < 1) gx = 1;
     p.slabs = (float*)workspace;
     auto kern = igemm_wgrad_kernel<T, NTAPS, QSRC, TD, TH, TW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-            MSSEG_FAIL(MSSEG_ELAUNCH, "wgrad: cannot set dynamic LDS size %d", C::LDS_BYTES);
-        attr_set = true;
-    }
+    static msseg_lds_attr_once attr;
+    if (!attr.ensure((const void*)kern, C::LDS_BYTES)) MSSEG_FAIL(MSSEG_ELAUNCH, "wgrad: cannot set dynamic LDS size %d", C::LDS_BYTES);
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, pairs, 1), dim3(256), C::LDS_BYTES, stream, p);
     MSSEG_CHECK_LAUNCH("igemm_wgrad");
     rp.slabs = p.slabs;

@@ -373,12 +373,8 @@ int msseg_stem_wgrad_grid(const StemWgParams& p) {
 
 int msseg_stem_wgrad_launch(const StemWgParams& p, int gx, hipStream_t stream) {
     const int lds = 2 * (P_BYTES + 3 * XS_ELEMS * 2 + 64);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)stem_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            MSSEG_FAIL(MSSEG_ELAUNCH, "stem_wgrad: cannot set dynamic LDS size %d", lds);
-        attr_set = true;
-    }
+    static msseg_lds_attr_once attr;
+    if (!attr.ensure((const void*)stem_wgrad_kernel, lds)) MSSEG_FAIL(MSSEG_ELAUNCH, "stem_wgrad: cannot set dynamic LDS size %d", lds);
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(gx, p.M / 32), dim3(W_THREADS), lds, stream, p);
     MSSEG_CHECK_LAUNCH("stem_wgrad");
     return MSSEG_OK;

@@ -288,7 +288,7 @@ def test_resume_from_reference_layout_checkpoint(tmp_path):
     ref = BasicUNet(1, 2, UNET_FEATURES["UNetSmall"])
     topt = torch.optim.AdamW(add_weight_decay(ref, 1e-5), lr=1e-3, betas=(0.9, 0.95), eps=1e-6)
     for _ in range(2):
-        ref(torch.randn(1, 1, 16, 16, 16)).square().mean().backward()
+        ref(torch.randn(1, 1, 32, 32, 32)).square().mean().backward()
         topt.step()
         topt.zero_grad()
     path = str(tmp_path / "ref_ckpt.pth")
@@ -309,7 +309,7 @@ def test_resume_from_reference_layout_checkpoint(tmp_path):
         assert torch.equal(opt.exp_avg_sq[off:off + k].cpu(), st["exp_avg_sq"].reshape(-1))
         off += k
     # one more step on both sides stays in agreement (bias correction uses the restored step count)
-    x = torch.randn(1, 1, 16, 16, 16)
+    x = torch.randn(1, 1, 32, 32, 32)
     ref(x).square().mean().backward()
     topt.step()
     net((x.to(DEV), None, None)).float().square().mean().backward()
