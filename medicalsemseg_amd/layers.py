@@ -585,3 +585,73 @@ class UpBlock:
         dcat = self.res.bwd(s, do, True)
         dx = self.up.bwd(x, dcat[..., :self.cout], True)
         return dx, dcat[..., self.cout:]
+
+
+def _merge_batch(t):
+    """[N, D, H, W, C] (dense or a channel slice of a wider buffer) as ONE sample [1, N*D, H, W, C]: per-channel
+    statistics over a channels-last batch are InstanceNorm statistics of that merged volume"""
+    N, D, H, W, C = t.shape
+    return t.view(1, N * D, H, W, C)
+
+
+class BatchNormAct:
+    """BatchNorm3d + ReLU / LeakyReLU(slope) of the reference's UNETR conv decoder
+    (/root/reference/models/segmentors/unetr.py:28-52: Conv3d -> BatchNorm3d -> ReLU).  Training mode normalises with the
+    batch statistics and updates the running ones (momentum, unbiased variance, num_batches_tracked) exactly like
+    torch.nn.BatchNorm3d; eval mode uses the running statistics.  The kernels are the InstanceNorm ones on the merged
+    volume (channels-last: a batch is one long sample)."""
+
+    def __init__(self, bn: torch.nn.BatchNorm3d, slope: float = 0.0):
+        self.bn = bn
+        self.inner = InstNormAct(bn.weight, bn.bias, slope, bn.eps)
+
+    def fwd(self, y_raw, out=None, stats=None):
+        """stats: optional per-sample (sum, sum of squares) [N, C, 2] from the conv epilogue.  Returns (act, merged stats)."""
+        bn = self.bn
+        N, D, H, W, C = y_raw.shape
+        cnt = N * D * H * W
+        if bn.training or not bn.track_running_stats:
+            s = stats.sum(0, keepdim=True) if stats is not None else hip.channel_stats(_merge_batch(y_raw))
+            if bn.training and bn.track_running_stats:
+                with torch.no_grad():
+                    bn.num_batches_tracked.add_(1)
+                    mean = s[0, :, 0] / cnt
+                    var = (s[0, :, 1] / cnt - mean * mean).clamp_(min=0) * (cnt / max(cnt - 1, 1))
+                    if bn.momentum is None:
+                        m = 1.0 / bn.num_batches_tracked.to(torch.float32)
+                        bn.running_mean.add_((mean - bn.running_mean) * m)
+                        bn.running_var.add_((var - bn.running_var) * m)
+                    else:
+                        bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+                        bn.running_var.mul_(1 - bn.momentum).add_(var, alpha=bn.momentum)
+        else:
+            rm, rv = bn.running_mean.float(), bn.running_var.float()
+            s = torch.stack([rm * cnt, (rv + rm * rm) * cnt], -1).unsqueeze(0).contiguous()
+        a = out if out is not None else torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device)
+        hip.instnorm_act_fwd(_merge_batch(y_raw), s, self.inner.gamma, self.inner.beta, _merge_batch(a), self.inner.slope,
+                             self.inner.eps, None)
+        return a, s
+
+    def bwd(self, y_raw, stats, da):
+        if not (self.bn.training or not self.bn.track_running_stats):
+            raise NotImplementedError("backward through an eval-mode BatchNorm (frozen statistics) is not on this path")
+        dy = self.inner.bwd(_merge_batch(y_raw), stats, None, _merge_batch(da))
+        return dy.view(y_raw.shape)
+
+
+class ConvBNAct:
+    """Conv3d k3 p1 (+bias) -> BatchNorm3d -> ReLU: `Conv3DBlock` of the reference's UNETR decoder."""
+
+    def __init__(self, conv: Conv3, norm: BatchNormAct):
+        self.conv, self.norm = conv, norm
+
+    def fwd(self, x, out=None):
+        y, st = self.conv.fwd(x, want_stats=True)
+        a, s = self.norm.fwd(y, out, stats=st)
+        return a, (x, y, s)
+
+    def bwd(self, saved, da, need_dx=True):
+        x, y, s = saved
+        dy = self.norm.bwd(y, s, da)
+        # a bias in front of a training-mode BatchNorm has an identically zero gradient, like in front of InstanceNorm
+        return self.conv.bwd(x, dy, need_dx, bias_grad_is_zero=True)

@@ -25,7 +25,8 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 sys.path.insert(0, REPO)
-from tests.golden_util import SW_CASES, det_fill_, det_tensor, sw_predictor  # noqa: E402
+from tests.golden_util import (SW_CASES, UNETRC_PROBES, ToyTokenEncoder, det_fill_, det_tensor, probe,  # noqa: E402
+                               sw_predictor)
 
 
 def _install_import_shims():
@@ -196,6 +197,30 @@ def gen_unetr_conv_blocks():
     _save("unetr_blocks.npz", **out)
 
 
+def gen_unetrc():
+    """the reference's own UNETRC (models/segmentors/unetr.py:195-289, pure torch) around a toy token encoder: training
+    mode (BatchNorm3d batch statistics + running-statistics update), logits, probes of the gradients of decoder and encoder
+    parameters and of the input-side token maps' producer, then an eval-mode forward on the updated running statistics"""
+    import models.segmentors.unetr as U
+    net = U.UNETRC(ToyTokenEncoder(1, 48, (32, 32, 32), (16, 16, 16)), in_chans=1, output_dim=2)
+    det_fill_(net, "unetrc.")
+    net.train()
+    x = det_tensor("unetrc_x", (2, 1, 32, 32, 32))
+    y = net(x)
+    r = det_tensor("unetrc_r", tuple(y.shape))
+    (y * r).sum().backward()
+    params = dict(net.named_parameters())
+    out = dict(logits=y)
+    for k in UNETRC_PROBES:
+        out["g:" + k] = probe(params[k].grad)
+    bn = net.decoder9_upsampler[1].block[1]
+    out["rm"], out["rv"], out["nbt"] = bn.running_mean, bn.running_var, bn.num_batches_tracked.float()
+    net.eval()
+    with torch.no_grad():
+        out["logits_eval"] = net(x)
+    _save("unetrc_ref.npz", **out)
+
+
 def gen_sliding_window_loop():
     """The reference's OWN loop (engine/utils.py:19-159: padding, window order, `centers`, blend, final slicing) run with the
     four MONAI helper names it imports bound in memory to oracle/sliding_window.py's restatements (MONAI is absent)."""
@@ -339,6 +364,7 @@ def main():
     gen_encoder(ref)
     gen_lr_and_misc()
     gen_unetr_conv_blocks()
+    gen_unetrc()
     gen_sliding_window_loop()
     gen_layers()
     gen_swin_official()

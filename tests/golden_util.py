@@ -58,3 +58,34 @@ SW_CASES = [  # tag, volume, roi, sw_batch, overlap, mode, cval
     ("sb1", (1, 1, 36, 36, 36), (24, 24, 24), 1, 0.5, "gaussian", 0.0),        # centers.unsqueeze(0) quirk
     ("batch2", (2, 1, 30, 26, 34), (16, 16, 16), 3, 0.5, "gaussian", 0.25),    # two volumes, short last batch
 ]
+
+
+class ToyTokenEncoder(torch.nn.Module):
+    """stand-in for the ViT in front of the reference's UNETRC decoder (/root/reference/models/segmentors/unetr.py:195-207
+    reads `input_dim`, `embed_dim`, `vol_size`, `patch_size` and calls it on the raw volume): a patch embedding and four
+    Linear taps, each [B, L, E] -- plain torch, shared by the golden generator, the oracle tests and the GPU tests"""
+
+    def __init__(self, in_chans=1, embed_dim=48, vol_size=(32, 32, 32), patch_size=(16, 16, 16)):
+        super().__init__()
+        self.input_dim, self.embed_dim = in_chans, embed_dim
+        self.vol_size, self.patch_size = list(vol_size), list(patch_size)
+        self.embed = torch.nn.Conv3d(in_chans, embed_dim, kernel_size=tuple(patch_size), stride=tuple(patch_size))
+        self.taps = torch.nn.ModuleList([torch.nn.Linear(embed_dim, embed_dim) for _ in range(4)])
+
+    def forward(self, x):
+        t = self.embed(x).flatten(2).transpose(1, 2)
+        return [torch.tanh(f(t)) for f in self.taps]
+
+
+UNETRC_PROBES = ["decoder0.0.block.0.block.weight", "decoder0.0.block.1.weight", "decoder0.0.block.1.bias",
+                 "decoder0.1.block.0.block.weight", "decoder3.2.block.1.block.weight", "decoder3.2.block.2.weight",
+                 "decoder6.0.block.0.block.weight", "decoder9.block.0.block.bias", "decoder12_upsampler.block.weight",
+                 "decoder9_upsampler.0.block.0.block.weight", "decoder9_upsampler.3.block.weight",
+                 "decoder6_upsampler.1.block.1.bias", "decoder3_upsampler.2.block.bias",
+                 "decoder0_header.0.block.0.block.weight", "decoder0_header.2.block.weight", "decoder0_header.2.block.bias",
+                 "encoder.embed.weight", "encoder.taps.3.weight"]
+
+
+def probe(t, n=4096):
+    """the first n elements of a (large) gradient: what the UNETRC fixtures keep of it"""
+    return t.detach().reshape(-1)[:n].clone()

@@ -317,3 +317,52 @@ def test_resume_from_reference_layout_checkpoint(tmp_path):
     num = sum(float(((p.detach().cpu() - rp.detach()) ** 2).sum()) for (p, _), rp in zip(opt._views, ref_params))
     den = sum(float((rp.detach() ** 2).sum()) for rp in ref_params)
     assert (num / den) ** 0.5 < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unetrc_vs_reference_golden(dtype):
+    """UNETR conv decoder (row A13) against the reference's own class (tests/golden/unetrc_ref.npz, generated by
+    oracle/gen_golden.py from /root/reference/models/segmentors/unetr.py): training-mode BatchNorm on the InstanceNorm
+    kernels, concat buffers written in place, gradients into decoder AND encoder parameters, running statistics, eval"""
+    from medicalsemseg_amd.models.unetrc import UNETRC
+    from tests.golden_util import UNETRC_PROBES, ToyTokenEncoder, det_fill_, det_tensor, probe
+    g = np.load(os.path.join(ROOT, "tests", "golden", "unetrc_ref.npz"))
+    net = UNETRC(ToyTokenEncoder(1, 48, (32, 32, 32), (16, 16, 16)), 1, 2, compute_dtype=dtype)
+    det_fill_(net, "unetrc.")
+    net = net.to(DEV).train()
+    x = det_tensor("unetrc_x", (2, 1, 32, 32, 32)).to(DEV)
+    y = net(x)
+    want = torch.from_numpy(g["logits"])
+    scale = float(want.abs().max())
+    err = float((y.float().cpu() - want).abs().max()) / scale
+    (y.float() * det_tensor("unetrc_r", tuple(y.shape)).to(DEV)).sum().backward()
+    params = dict(net.named_parameters())
+    worst = 0.0
+    for k in UNETRC_PROBES:
+        w = torch.from_numpy(g["g:" + k])
+        got = probe(params[k].grad).float().cpu()
+        if float(w.abs().max()) < 1e-6:      # biases in front of a training-mode BatchNorm: exactly zero here
+            assert float(got.abs().max()) < 1e-3, k
+            continue
+        e = float((got - w).norm() / w.norm())
+        print(f"   {k}: rel-L2 {e:.3e} (|g| {float(w.norm()):.3e})")
+        worst = max(worst, e)
+    print(f"[{dtype}] UNETRC 32^3: logits err/scale {err:.3e}, worst grad-probe rel-L2 {worst:.3e}")
+    bn = net.decoder9_upsampler[1].block[1]
+    assert float(bn.num_batches_tracked) == float(g["nbt"])
+    # Gradient tolerance: this network (ReLU after BatchNorm over as few as 16 values per channel at the 2^3 level) is
+    # ill-conditioned in its gradients -- the oracle's stock torch ops run in fp32 on the GPU differ from the CPU golden by
+    # 4e-4 ... 5.4e-3 on these probes (tools/unetrc_cond.py) while the logits agree to 4e-6; the HIP path shows the same
+    # 1.5e-3 ... 4.6e-3.  The gate is therefore the logits (2e-4) and the head / BatchNorm kernels' own exact tests.
+    if dtype == torch.float32:
+        assert err < 2e-4 and worst < 1e-2
+        assert np.allclose(bn.running_mean.cpu().numpy(), g["rm"], rtol=1e-3, atol=1e-4)
+        assert np.allclose(bn.running_var.cpu().numpy(), g["rv"], rtol=1e-3, atol=1e-4)
+    else:
+        assert err < 5e-2 and worst < 0.5      # bf16 drift on the same ill-conditioned probes, reported above
+    net.eval()
+    with torch.no_grad():
+        ye = net(x).float().cpu()
+    we = torch.from_numpy(g["logits_eval"])
+    ee = float((ye - we).abs().max()) / float(we.abs().max())
+    assert ee < (2e-4 if dtype == torch.float32 else 6e-2), ee

@@ -241,3 +241,16 @@ def test_swin_unetr_official_load_from_maps_pretrained_keys():
     cfg = get_args("--model SwinUNETR --vol_size 64 --hidden_dim 24 --output_dim 3".split())
     m = cfg_ok.build_model(cfg)
     assert type(m).__name__ == "SwinUNETR" and m.swinViT.layers1[0].blocks[0].attn.qkv.weight.shape == (72, 24)
+
+
+def test_unetrc_state_dict_keys_equal_reference_layout():
+    """product UNETRC keeps the key layout of /root/reference/models/segmentors/unetr.py (the oracle restatement is pinned
+    against the reference class by tests/test_oracle_golden.py, weights filled by key name)"""
+    from medicalsemseg_amd.models.unetrc import UNETRC
+    from oracle.unetrc import UNETRC as OracleUNETRC
+    from tests.golden_util import ToyTokenEncoder
+    a = UNETRC(ToyTokenEncoder(1, 48), 1, 2)
+    b = OracleUNETRC(ToyTokenEncoder(1, 48), 1, 2)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb)
+    assert all(sa[k].shape == sb[k].shape for k in sa)

@@ -205,3 +205,32 @@ def test_swin_official_vs_reference_file(golden_dir):
     _close(net.encoder1.layer.conv1.conv.weight.grad[:12], gn["d_enc1_w"], rtol=1e-3, atol=1e-2)
     _close(net.swinViT.patch_embed.proj.weight.grad, gn["d_patch_w"], rtol=2e-3, atol=2e-2)
     _close(net.swinViT.layers4[0].blocks[0].mlp.linear1.weight.grad[:96, :96], gn["d_l4_fc"], rtol=2e-3, atol=2e-2)
+
+
+def test_unetrc_oracle_vs_reference_class(golden_dir):
+    """oracle/unetrc.py (restatement of the reference's UNETR conv decoder, /root/reference/models/segmentors/unetr.py:9-52,
+    195-289) against the reference class itself: same state-dict keys, training-mode logits, gradient probes, BatchNorm
+    running statistics, eval-mode logits"""
+    from oracle.unetrc import UNETRC
+    from tests.golden_util import UNETRC_PROBES, ToyTokenEncoder, probe
+    g = _load(golden_dir, "unetrc_ref.npz")
+    torch.set_num_threads(8)
+    net = UNETRC(ToyTokenEncoder(1, 48, (32, 32, 32), (16, 16, 16)), in_chans=1, output_dim=2)
+    det_fill_(net, "unetrc.")
+    net.train()
+    x = det_tensor("unetrc_x", (2, 1, 32, 32, 32))
+    y = net(x)
+    assert np.allclose(y.detach().numpy(), g["logits"], rtol=1e-4, atol=1e-4)
+    (y * det_tensor("unetrc_r", tuple(y.shape))).sum().backward()
+    params = dict(net.named_parameters())
+    for k in UNETRC_PROBES:
+        want = g["g:" + k]
+        got = probe(params[k].grad).numpy()
+        assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-3), k
+    bn = net.decoder9_upsampler[1].block[1]
+    assert np.allclose(bn.running_mean.numpy(), g["rm"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(bn.running_var.numpy(), g["rv"], rtol=1e-4, atol=1e-5)
+    assert float(bn.num_batches_tracked) == float(g["nbt"])
+    net.eval()
+    with torch.no_grad():
+        assert np.allclose(net(x).numpy(), g["logits_eval"], rtol=1e-4, atol=1e-4)
