@@ -305,7 +305,7 @@ def main():
     elif args.workload == "swin_unetr_official":
         from medicalsemseg_amd.models.swin_unetr_official import SwinUNETR
         net = SwinUNETR((args.size,) * 3, 1, args.classes, feature_size=48, compute_dtype=dtype).to(dev)
-        args.no_graph = True     # torch pad / slice / cat ops of the window padding and patch merging stay eager
+        args.no_graph = args.no_graph or bool(os.environ.get("MSSEG_SWIN_NO_GRAPH"))
     else:
         net = UNet(1, args.classes, compute_dtype=dtype).to(dev)
     opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=4e-4, betas=(0.9, 0.95), eps=1e-6)

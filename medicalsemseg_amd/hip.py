@@ -35,6 +35,8 @@ SIGNATURES = {
     "msseg_conv3d_k3_variant": ([_i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_kernel": ([_i, _i, _i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
+    "msseg_dwconv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_dwconv3d_k3_wgrad": ([_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_reduce_scratch_bytes": ([], _sz),
     "msseg_conv3d_k3_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll, _vp, _f, _f, _vp,
                                      _vp, _vp, _i, _vp, _sz, _i, _vp], _i),
@@ -572,6 +574,24 @@ def _nsc(x):
     return N, x.numel() // (N * C), C
 
 
+def dwconv3d_k3(x, w_taps, bias, y, flip=False):
+    """depthwise conv k3 p1 on channels-last x; w_taps fp32 [27, C] (tap-major); flip: the input gradient"""
+    _need_gpu(x, w_taps, y)
+    N, D, H, W, C = x.shape
+    _ck(lib().msseg_dwconv3d_k3_fwd(_p(x), ld(x), _p(w_taps), _p(bias), _p(y), ld(y), N, D, H, W, C, int(flip), dt(x),
+                                    _stream()), "dwconv3d_k3_fwd")
+    return y
+
+
+def dwconv3d_k3_wgrad(x, dy, dw, dbias, acc_w=False, acc_b=False):
+    """dw fp32 [C, 1, 3, 3, 3], dbias fp32 [C] (either may be None)"""
+    _need_gpu(x, dy)
+    N, D, H, W, C = x.shape
+    sc = scratch(x.device)
+    _ck(lib().msseg_dwconv3d_k3_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), _p(dbias), int(acc_w), int(acc_b), N, D, H, W, C,
+                                      _p(sc), sc.numel(), dt(x), _stream()), "dwconv3d_k3_wgrad")
+
+
 def channel_stats(x, stats=None):
     _need_gpu(x)
     N, S, Cc = _nsc(x)
@@ -628,6 +648,14 @@ def instnorm_act_bwd(x, stats, gamma, y, dy, dx, slope, eps=1e-5, dres=None, dga
     """dx (and dres) from dy; the affine gradients dgamma/dbeta (fp32 [C]) are written (or accumulated) by the
     reduce kernel's finalising block.  Returns red[N][C][2] = (sum dz, sum dz*xhat)."""
     _need_gpu(x, stats, dy, dx)
+    red = instnorm_act_bwd_reduce(x, stats, gamma, y, dy, slope, eps, dgamma, dbeta, accumulate, beta)
+    instnorm_act_bwd_apply(x, stats, gamma, y, dy, red, dx, slope, eps, dres, beta)
+    return red
+
+
+def instnorm_act_bwd_reduce(x, stats, gamma, y, dy, slope, eps=1e-5, dgamma=None, dbeta=None, accumulate=False, beta=None):
+    """first half of instnorm_act_bwd: red[N][C][2] = (sum dz, sum dz*xhat) (+ dgamma / dbeta)"""
+    _need_gpu(x, stats, dy)
     N, S, Cc = _nsc(x)
     red = torch.empty(N, Cc, 2, dtype=torch.float32, device=x.device)
     sc = scratch(x.device)
@@ -635,7 +663,6 @@ def instnorm_act_bwd(x, stats, gamma, y, dy, dx, slope, eps=1e-5, dres=None, dga
                                             ld(y) if y is not None else 0, _p(dy), ld(dy), _p(red),
                                             _p(dgamma), _p(dbeta), int(accumulate), N, S, Cc, eps, slope, _p(sc),
                                             sc.numel(), dt(x), _stream()), "instnorm_act_bwd_reduce")
-    instnorm_act_bwd_apply(x, stats, gamma, y, dy, red, dx, slope, eps, dres, beta)
     return red
 
 

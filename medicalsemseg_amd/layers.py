@@ -595,28 +595,50 @@ def _merge_batch(t):
 
 
 class BatchNormAct:
-    """BatchNorm3d + ReLU / LeakyReLU(slope) of the reference's UNETR conv decoder
-    (/root/reference/models/segmentors/unetr.py:28-52: Conv3d -> BatchNorm3d -> ReLU).  Training mode normalises with the
-    batch statistics and updates the running ones (momentum, unbiased variance, num_batches_tracked) exactly like
-    torch.nn.BatchNorm3d; eval mode uses the running statistics.  The kernels are the InstanceNorm ones on the merged
-    volume (channels-last: a batch is one long sample)."""
+    """BatchNorm3d + ReLU / LeakyReLU(slope) (slope 1: no activation) of the reference's UNETR conv decoder
+    (/root/reference/models/segmentors/unetr.py:28-52) and of the SwinDepth MLP (models/backbones/swindepth.py:42-44).
+    Training mode normalises with the batch statistics and updates the running ones (momentum, unbiased variance,
+    num_batches_tracked) exactly like torch.nn.BatchNorm3d; eval mode uses the running statistics.  The kernels are the
+    InstanceNorm ones on the merged volume (channels-last: a batch is one long sample).
 
-    def __init__(self, bn: torch.nn.BatchNorm3d, slope: float = 0.0):
+    `group` (a torch.distributed process group, or True for the default one) makes it SyncBatchNorm -- the reference
+    converts every BatchNorm under DDP (/root/reference/run_training.py:83): the per-channel sums of the forward and
+    the two sums of the backward are all-reduced ([C, 2] floats each), everything else stays local."""
+
+    def __init__(self, bn: torch.nn.BatchNorm3d, slope: float = 0.0, group=None):
         self.bn = bn
         self.inner = InstNormAct(bn.weight, bn.bias, slope, bn.eps)
+        self.group = group
+
+    def _all_reduce(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, group=None if self.group is True else self.group)
+
+    def _synced(self):
+        import torch.distributed as dist
+        if self.group is None or not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(None if self.group is True else self.group) > 1
 
     def fwd(self, y_raw, out=None, stats=None):
-        """stats: optional per-sample (sum, sum of squares) [N, C, 2] from the conv epilogue.  Returns (act, merged stats)."""
+        """stats: optional per-sample (sum, sum of squares) [N, C, 2] from the conv epilogue.  Returns (act, saved stats);
+        the saved statistics are scaled so that the kernels' local element count yields the (global) mean / variance."""
         bn = self.bn
         N, D, H, W, C = y_raw.shape
         cnt = N * D * H * W
         if bn.training or not bn.track_running_stats:
             s = stats.sum(0, keepdim=True) if stats is not None else hip.channel_stats(_merge_batch(y_raw))
+            total = cnt
+            if self._synced():
+                pack = torch.cat([s.reshape(-1), torch.full((1,), float(cnt), device=s.device)])
+                self._all_reduce(pack)
+                total = float(pack[-1])          # host sync: SyncBatchNorm runs eagerly
+                s = (pack[:-1] * (cnt / total)).reshape(1, C, 2)
             if bn.training and bn.track_running_stats:
                 with torch.no_grad():
                     bn.num_batches_tracked.add_(1)
                     mean = s[0, :, 0] / cnt
-                    var = (s[0, :, 1] / cnt - mean * mean).clamp_(min=0) * (cnt / max(cnt - 1, 1))
+                    var = (s[0, :, 1] / cnt - mean * mean).clamp_(min=0) * (total / max(total - 1, 1))
                     if bn.momentum is None:
                         m = 1.0 / bn.num_batches_tracked.to(torch.float32)
                         bn.running_mean.add_((mean - bn.running_mean) * m)
@@ -635,7 +657,19 @@ class BatchNormAct:
     def bwd(self, y_raw, stats, da):
         if not (self.bn.training or not self.bn.track_running_stats):
             raise NotImplementedError("backward through an eval-mode BatchNorm (frozen statistics) is not on this path")
-        dy = self.inner.bwd(_merge_batch(y_raw), stats, None, _merge_batch(da))
+        if not self._synced():
+            dy = self.inner.bwd(_merge_batch(y_raw), stats, None, _merge_batch(da))
+            return dy.view(y_raw.shape)
+        n = self.inner
+        ym, dam = _merge_batch(y_raw), _merge_batch(da)
+        dg, db, acc = _norm_grad_bufs(n)
+        red = hip.instnorm_act_bwd_reduce(ym, stats, n.gamma, None, dam, n.slope, n.eps, dg, db, acc, n.beta)
+        cnt = float(y_raw.numel() // y_raw.shape[-1])
+        pack = torch.cat([red.reshape(-1), torch.full((1,), cnt, device=red.device)])
+        self._all_reduce(pack)
+        red = (pack[:-1] * (cnt / pack[-1])).reshape(red.shape).contiguous()
+        dy = torch.empty(ym.shape, dtype=ym.dtype, device=ym.device)
+        hip.instnorm_act_bwd_apply(ym, stats, n.gamma, None, dam, red, dy, n.slope, n.eps, None, n.beta)
         return dy.view(y_raw.shape)
 
 

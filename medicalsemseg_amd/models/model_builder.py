@@ -5,6 +5,8 @@ for the models on the hot path.
   UNet).
 * ``cfg.model == 'nnFormerUNETR'`` -- ``SwinTransformerNNFormer`` encoder + ``SwinUNETRCustom`` decoder, the branch
   at ``model_builder.py:15-66``.
+* ``cfg.model == 'SwinDepth'`` -- the same wiring around the ``SwinDepth`` encoder (depthwise-conv + BatchNorm MLP), the
+  branch at ``model_builder.py:120-171``.
 * ``cfg.model == 'SwinUNETR'`` -- the vendored MONAI variant of ``models/segmentors/swin_unetr_official.py`` (window 7,
   ``feature_size = cfg.hidden_dim``), the literal "Swin-UNETR 48-feat" of BASELINE.json configs[3] (the reference keeps
   the class but wires no ``build_model`` branch to it).
@@ -17,7 +19,7 @@ import torch
 
 from .unet import UNET_FEATURES, UNet
 
-OUT_OF_SCOPE = ("SwInception", "SwinDepth", "SwinSegFormer", "SegFormer3D", "GCViTUNETR", "FocalNetUNETR")
+OUT_OF_SCOPE = ("SwInception", "SwinSegFormer", "SegFormer3D", "GCViTUNETR", "FocalNetUNETR")
 
 
 def _dtype(cfg):
@@ -37,16 +39,17 @@ def build_model(cfg):
     name = cfg.model
     if name in UNET_FEATURES:
         return UNet(cfg.in_chans, cfg.output_dim, UNET_FEATURES[name], compute_dtype=_dtype(cfg))
-    if name == "nnFormerUNETR":
-        from .swin_unetr import SwinTransformerNNFormer, SwinUNETRCustom
+    if name in ("nnFormerUNETR", "SwinDepth"):
+        from .swin_unetr import SwinDepth, SwinTransformerNNFormer, SwinUNETRCustom
         for flag in ("learned_cls_vectors", "rel_pos_bias_affine", "rel_crop_pos_emb", "abs_pos_emb", "global_token"):
             if getattr(cfg, flag, False):
                 raise NotImplementedError(f"--{flag} is outside the hot-path scope of this build (SURVEY.md section 2)")
         ws = cfg.window_size if isinstance(cfg.window_size, (tuple, list)) else (cfg.window_size,) * len(cfg.depths)
-        encoder = SwinTransformerNNFormer(pretrain_img_size=_t3(cfg.vol_size), patch_size=_t3(cfg.patch_size),
-                                          in_chans=cfg.in_chans, embed_dim=cfg.hidden_dim, depths=tuple(cfg.depths),
-                                          num_heads=tuple(cfg.num_heads), window_size=tuple(ws), qkv_bias=cfg.qkv_bias,
-                                          mlp_ratio=getattr(cfg, "mlp_ratio", 4.0), compute_dtype=_dtype(cfg))
+        enc_cls = SwinDepth if name == "SwinDepth" else SwinTransformerNNFormer      # model_builder.py:120-171
+        encoder = enc_cls(pretrain_img_size=_t3(cfg.vol_size), patch_size=_t3(cfg.patch_size), in_chans=cfg.in_chans,
+                          embed_dim=cfg.hidden_dim, depths=tuple(cfg.depths), num_heads=tuple(cfg.num_heads),
+                          window_size=tuple(ws), qkv_bias=cfg.qkv_bias, mlp_ratio=getattr(cfg, "mlp_ratio", 4.0),
+                          compute_dtype=_dtype(cfg))
         return SwinUNETRCustom(encoder, in_channels=cfg.in_chans, out_channels=cfg.output_dim,
                                img_size=_t3(cfg.vol_size), hidden_size=cfg.hidden_dim, patch_size=_t3(cfg.patch_size),
                                compute_dtype=_dtype(cfg))
@@ -56,5 +59,5 @@ def build_model(cfg):
                          num_heads=tuple(cfg.num_heads), feature_size=cfg.hidden_dim, compute_dtype=_dtype(cfg))
     if name in OUT_OF_SCOPE:
         raise NotImplementedError(f"model '{name}' is a research variant outside this build's hot-path scope "
-                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR', 'SwinUNETR']")
+                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR', 'SwinDepth', 'SwinUNETR']")
     raise ValueError(f"unknown cfg.model '{name}'")

@@ -40,6 +40,29 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
 
+class _DepthMlp(nn.Module):
+    """MLP of SwinDepth (/root/reference/models/backbones/swindepth.py:25-73): fc1 -> GELU -> 3 x (depthwise Conv3d k3
+    -> BatchNorm3d(eps 1e-3) -> GELU) on the token volume -> fc2.  Tokens are channels-last volumes here, so the
+    reference's permute / reshape pairs around the convolutions do not exist."""
+
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        for i in (1, 2, 3):
+            self.add_module(f"dwc{i}", nn.Conv3d(hidden, hidden, kernel_size=3, padding=1, groups=hidden))
+        for i in (1, 2, 3):
+            self.add_module(f"bn{i}", nn.BatchNorm3d(hidden, eps=0.001))
+        self.fc2 = nn.Linear(hidden, dim)
+        self.sync_group = None      # set to a process group (or True) for SyncBatchNorm under data parallelism
+
+    def run(self, y):
+        y = ops.gelu(ops.linear(y, self.fc1.weight, self.fc1.bias))
+        for i in (1, 2, 3):
+            conv, bn = getattr(self, f"dwc{i}"), getattr(self, f"bn{i}")
+            y = ops.gelu(ops.batch_norm(ops.dwconv3(y, conv.weight, conv.bias), bn, self.sync_group))
+        return ops.linear(y, self.fc2.weight, self.fc2.bias)
+
+
 class _WindowAttention(nn.Module):
     def __init__(self, dim, ws, heads, qkv_bias):
         super().__init__()
@@ -52,7 +75,7 @@ class _WindowAttention(nn.Module):
 
 
 class _Block(nn.Module):
-    def __init__(self, dim, res, heads, ws, shift, mlp_ratio, qkv_bias, drop_path):
+    def __init__(self, dim, res, heads, ws, shift, mlp_ratio, qkv_bias, drop_path, mlp="plain"):
         super().__init__()
         self.res = tuple(res)
         if min(self.res) <= ws:          # swin_nnformer.py:213-216
@@ -61,7 +84,7 @@ class _Block(nn.Module):
         self.norm1 = nn.LayerNorm(dim)
         self.attn = _WindowAttention(dim, ws, heads, qkv_bias)
         self.norm2 = nn.LayerNorm(dim)
-        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.mlp = _DepthMlp(dim, int(dim * mlp_ratio)) if mlp == "depth" else _Mlp(dim, int(dim * mlp_ratio))
 
     def _dp_scale(self, x):
         """per-sample stochastic-depth factor mask[b] / keep (models/layers/drop_path.py:15-45), or None; the multiply
@@ -82,8 +105,11 @@ class _Block(nn.Module):
         y = ops.linear(y, a.proj.weight, a.proj.bias)
         x = ops.add(x, y, self._dp_scale(x))
         y = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        y = ops.gelu(ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
-        y = ops.linear(y, self.mlp.fc2.weight, self.mlp.fc2.bias)
+        if isinstance(self.mlp, _DepthMlp):
+            y = self.mlp.run(y)
+        else:
+            y = ops.gelu(ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
+            y = ops.linear(y, self.mlp.fc2.weight, self.mlp.fc2.bias)
         return ops.add(x, y, self._dp_scale(x))
 
 
@@ -99,10 +125,10 @@ class _PatchMerging(nn.Module):
 
 
 class _BasicLayer(nn.Module):
-    def __init__(self, dim, res, depth, heads, ws, mlp_ratio, qkv_bias, drop_path):
+    def __init__(self, dim, res, depth, heads, ws, mlp_ratio, qkv_bias, drop_path, mlp="plain"):
         super().__init__()
         self.blocks = nn.ModuleList([_Block(dim, res, heads, ws, 0 if i % 2 == 0 else ws // 2, mlp_ratio, qkv_bias,
-                                            drop_path[i]) for i in range(depth)])
+                                            drop_path[i], mlp) for i in range(depth)])
         self.downsample = _PatchMerging(dim)
 
     def forward(self, x):
@@ -131,7 +157,7 @@ class SwinTransformerNNFormer(nn.Module):
     def __init__(self, pretrain_img_size=(96, 96, 96), patch_size=(2, 2, 2), in_chans=1, embed_dim=48,
                  depths: Sequence[int] = (2, 2, 2, 2), num_heads: Sequence[int] = (3, 6, 12, 24),
                  window_size: Sequence[int] = (6, 6, 6, 3), mlp_ratio=4.0, qkv_bias=True, drop_path_rate=0.2,
-                 compute_dtype=torch.bfloat16):
+                 compute_dtype=torch.bfloat16, mlp="plain"):
         super().__init__()
         self.num_layers, self.embed_dim, self.compute_dtype = len(depths), embed_dim, compute_dtype
         self.patch_embed = _PatchEmbed3D(patch_size, in_chans, embed_dim)
@@ -140,7 +166,7 @@ class SwinTransformerNNFormer(nn.Module):
         for i in range(self.num_layers):
             res = tuple(pretrain_img_size[d] // patch_size[d] // 2 ** i for d in range(3))
             self.layers.append(_BasicLayer(embed_dim * 2 ** i, res, depths[i], num_heads[i], window_size[i], mlp_ratio,
-                                           qkv_bias, dpr[sum(depths[:i]):sum(depths[:i + 1])]))
+                                           qkv_bias, dpr[sum(depths[:i]):sum(depths[:i + 1])], mlp))
         self.num_features = [embed_dim * 2 ** (i + 1) for i in range(self.num_layers)]
         for i in range(self.num_layers):
             self.add_module(f"norm{i}", nn.LayerNorm(self.num_features[i]))
@@ -162,6 +188,22 @@ class SwinTransformerNNFormer(nn.Module):
             n = getattr(self, f"norm{i}")
             feats.append(ops.layer_norm(x, n.weight, n.bias, n.eps))   # norm of the DOWNSAMPLED tensor (:653-658)
         return feats, x_cl
+
+
+class SwinDepth(SwinTransformerNNFormer):
+    """/root/reference/models/backbones/swindepth.py:400-691 with its default-off extras off (learned class vectors,
+    affine / crop position terms, global token): the reference's Swin encoder whose MLP carries three depthwise
+    Conv3d + BatchNorm3d + GELU stages (`_DepthMlp`).  `sync_batchnorm(group)` = what run_training.py:83 does under DDP."""
+
+    def __init__(self, *a, **k):
+        k["mlp"] = "depth"
+        super().__init__(*a, **k)
+
+    def sync_batchnorm(self, group=True):
+        for m in self.modules():
+            if isinstance(m, _DepthMlp):
+                m.sync_group = group
+        return self
 
 
 # ------------------------------------------------------------------------------------------------------------

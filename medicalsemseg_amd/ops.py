@@ -247,6 +247,60 @@ class PatchConvFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class DwConv3Fn(torch.autograd.Function):
+    """depthwise Conv3d k3 p1 (groups = channels) on a token volume [B, S, H, W, C]; weight [C, 1, 3, 3, 3] (+bias):
+    nn.Conv3d(C, C, 3, padding=1, groups=C) of /root/reference/models/backbones/swindepth.py:36-41"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _c(x)
+        C = x.shape[-1]
+        taps = weight.detach().reshape(C, 27).t().contiguous().float()      # tap-major fp32 [27, C]
+        ctx.save_for_backward(x, taps)
+        ctx.weight, ctx.bias = weight, bias
+        return hip.dwconv3d_k3(x, taps, bias.detach().float() if bias is not None else None, torch.empty_like(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, taps = ctx.saved_tensors
+        dy = _c(dy)
+        w, b = ctx.weight, ctx.bias
+        want_w, want_b = w.requires_grad, b is not None and b.requires_grad
+        if want_w or want_b:
+            gw, aw = _gbuf(w) if want_w else (None, False)
+            gb, ab = _gbuf(b) if want_b else (None, False)
+            hip.dwconv3d_k3_wgrad(x, dy, gw, gb, aw, ab)
+        dx = hip.dwconv3d_k3(dy, taps, None, torch.empty_like(dy), flip=True) if ctx.needs_input_grad[0] else None
+        return dx, None, None
+
+
+class BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm3d on a channels-last volume (layers.BatchNormAct: training statistics + running-statistics update,
+    eval statistics, optional cross-rank synchronisation); `weight` / `bias` are passed so autograd sees the parameters"""
+
+    @staticmethod
+    def forward(ctx, x, bn, weight, bias, group):
+        x = _c(x)
+        op = layers.BatchNormAct(bn, 1.0, group)
+        y, stats = op.fwd(x)
+        ctx.op = op
+        ctx.save_for_backward(x, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        return ctx.op.bwd(x, stats, _c(dy)), None, None, None, None
+
+
+def dwconv3(x, weight, bias=None):
+    return DwConv3Fn.apply(x, weight, bias)
+
+
+def batch_norm(x, bn, group=None):
+    return BatchNormFn.apply(x, bn, bn.weight, bn.bias, group)
+
+
 def linear(x, weight, bias=None):
     return LinearFn.apply(x, weight, bias)
 

@@ -151,6 +151,32 @@ def gen_encoder(ref):
               **{f"out{i}": o for i, o in enumerate(outs)})
 
 
+def gen_swindepth():
+    """the reference's SwinDepth encoder (models/backbones/swindepth.py:400-691; learned class vectors off, as build_model
+    passes cfg.learned_cls_vectors = False): depthwise-conv + BatchNorm MLP in TRAINING mode (batch statistics, running
+    statistics updated), stochastic depth 0; features + gradients, then the eval-mode features on the updated statistics"""
+    import models.backbones.swindepth as SD
+    vol = (24, 24, 24)
+    m = SD.SwinDepth(pretrain_img_size=vol, patch_size=(2, 2, 2), in_chans=1, embed_dim=32, depths=[2, 2],
+                     num_heads=[2, 4], window_size=[6, 3], drop_path_rate=0.0, use_learned_cls_vectors=False,
+                     out_indices=(0, 1))
+    det_fill_(m, "sd")
+    m.train()
+    x = det_tensor("sd_x", (2, 1) + vol).requires_grad_(True)
+    outs = m((x, None, None))
+    loss = sum((o * det_tensor(f"sd_r{i}", o.shape)).sum() for i, o in enumerate(outs))
+    loss.backward()
+    mlp = m.layers[0].blocks[1].mlp
+    out = dict(dx=x.grad, d_dwc2_w=mlp.dwc2.weight.grad, d_dwc2_b=mlp.dwc2.bias.grad, d_bn2_w=mlp.bn2.weight.grad,
+               d_bn2_b=mlp.bn2.bias.grad, d_fc1_w=mlp.fc1.weight.grad, d_fc2_w=m.layers[1].blocks[0].mlp.fc2.weight.grad,
+               rm=mlp.bn3.running_mean, rv=mlp.bn3.running_var, **{f"out{i}": o for i, o in enumerate(outs)})
+    m.eval()
+    with torch.no_grad():
+        for i, o in enumerate(m((x.detach(), None, None))):
+            out[f"eval{i}"] = o
+    _save("swindepth_encoder.npz", **out)
+
+
 def gen_lr_and_misc():
     from models.optimizers.lr_scheduler import LinearWarmupCosineAnnealingLR
     import utils.misc as misc
@@ -362,6 +388,7 @@ def main():
     gen_block(ref)
     gen_basic_layer_mask(ref)
     gen_encoder(ref)
+    gen_swindepth()
     gen_lr_and_misc()
     gen_unetr_conv_blocks()
     gen_unetrc()

@@ -366,3 +366,16 @@ def test_unetrc_vs_reference_golden(dtype):
     we = torch.from_numpy(g["logits_eval"])
     ee = float((ye - we).abs().max()) / float(we.abs().max())
     assert ee < (2e-4 if dtype == torch.float32 else 6e-2), ee
+
+
+def test_sync_batchnorm_two_ranks_share_one_gpu_over_gloo():
+    """SyncBatchNorm (reference: run_training.py:83 converts every BatchNorm under DDP): two ranks with half a batch each
+    reproduce the whole-batch BatchNorm -- output, input gradient, affine gradients after the gradient exchange, running
+    statistics"""
+    env = dict(os.environ, MSSEG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200),
+                        os.path.join(ROOT, "tools", "syncbn_check.py")], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "SYNCBN_CHECK_OK" in r.stdout

@@ -811,3 +811,76 @@ def test_device_crop_augment_bit_exact_vs_oracle():
     from medicalsemseg_amd.utils import misc
     rel = misc.get_rel_crop_loc(batch["image_transforms"][0])
     assert tuple(rel.shape) == (6, 3) and float(rel.min()) > 0 and float(rel.max()) < 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batchnorm_act_vs_torch(dtype):
+    """BatchNorm3d + ReLU (training: batch statistics, running-statistics update; eval: running statistics) on the
+    InstanceNorm kernels over the merged batch, dense and as a channel slice of a concat buffer, vs torch.nn.BatchNorm3d"""
+    from medicalsemseg_amd import layers
+    dev = _dev()
+    N, C, sp = 3, 32, (8, 12, 16)
+    x = gen(N, C, *sp, seed=21, scale=1.5) + 0.3
+    r = gen(N, C, *sp, seed=22)
+    xr = rnd(dtype, x)
+    mk = lambda: torch.nn.BatchNorm3d(C)
+    ref, mine = mk(), mk().to(dev)
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.1 * gen(C, seed=23)); ref.bias.copy_(0.1 * gen(C, seed=24))
+    mine.load_state_dict(ref.state_dict())
+    xr = xr.clone().requires_grad_(True)
+    y = torch.relu(ref(xr))
+    (y * rnd(dtype, r)).sum().backward()
+    op = layers.BatchNormAct(mine, 0.0)
+    big = torch.zeros(N, *sp, 2 * C, dtype=dtype, device=dev)
+    xg = cl(x, dtype, dev)
+    a, s = op.fwd(xg, out=big[..., C:])
+    check(ncdhw(big[..., C:]), y.detach(), dtype, "batchnorm fwd (into a concat slice)")
+    assert float(big[..., :C].float().abs().max()) == 0
+    dgrid = torch.zeros(N, *sp, 2 * C, dtype=dtype, device=dev)
+    dgrid[..., :C] = cl(r, dtype, dev)
+    dy = op.bwd(xg, s, dgrid[..., :C])
+    check(ncdhw(dy), xr.grad, dtype, "batchnorm bwd")
+    check(mine.weight.grad, ref.weight.grad, dtype, "batchnorm dgamma")
+    check(mine.bias.grad, ref.bias.grad, dtype, "batchnorm dbeta")
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(mine.running_mean.cpu(), ref.running_mean, atol=tol) and torch.allclose(mine.running_var.cpu(), ref.running_var, atol=tol)
+    assert int(mine.num_batches_tracked) == 1
+    ref.eval(); mine.eval()
+    with torch.no_grad():
+        ye = torch.relu(ref(rnd(dtype, x)))
+    ae, _ = op.fwd(xg)
+    check(ncdhw(ae), ye, dtype, "batchnorm eval fwd")
+    with pytest.raises(NotImplementedError):
+        op.bwd(xg, s, dgrid[..., :C])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,sp", [(128, (12, 12, 12)), (192, (6, 6, 6)), (40, (5, 7, 9)), (1536, (3, 3, 3))])
+def test_dwconv3_vs_torch(dtype, C, sp):
+    """depthwise Conv3d k3 p1 (groups = C) forward, input gradient, weight + bias gradient (deterministic two-stage sums)
+    vs torch.nn.functional.conv3d(groups=C); a second backward accumulates"""
+    from medicalsemseg_amd import ops
+    dev = _dev()
+    N = 2
+    x = gen(N, C, *sp, seed=31)
+    w = gen(C, 1, 3, 3, 3, seed=32, scale=27 ** -0.5)
+    b = gen(C, seed=33)
+    r = gen(N, C, *sp, seed=34)
+    xr, rr = rnd(dtype, x, r)
+    xr = xr.clone().requires_grad_(True)      # rnd() returns the input itself for fp32
+    wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    yref = F.conv3d(xr, wr, br, padding=1, groups=C)
+    yref.backward(rr)
+    wp = torch.nn.Parameter(w.to(dev)); bp = torch.nn.Parameter(b.to(dev))
+    xg = cl(x, dtype, dev).requires_grad_(True)
+    y = ops.dwconv3(xg, wp, bp)
+    check(ncdhw(y), yref.detach(), dtype, "dwconv3 fwd")
+    y.backward(cl(r, dtype, dev))
+    check(ncdhw(xg.grad), xr.grad, dtype, "dwconv3 dgrad")
+    check(wp.grad, wr.grad, dtype, "dwconv3 wgrad")
+    check(bp.grad, br.grad, dtype, "dwconv3 bias grad")
+    g1 = wp.grad.clone()
+    y2 = ops.dwconv3(xg, wp, bp)
+    y2.backward(cl(r, dtype, dev))
+    assert torch.equal(wp.grad, 2 * g1)          # accumulate path; fixed-order sums -> bit-identical second pass

@@ -326,3 +326,42 @@ def test_drop_path_residual_add_vs_reference_golden(golden_dir):
     t = blk(xin)
     assert torch.equal(t[1], xin[1]) and torch.equal(t[3], xin[3])      # dropped samples keep the shortcut only
     assert not torch.equal(t[0], e1[0])                                 # kept samples: branch scaled by 1 / keep
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swindepth_encoder_vs_reference_golden(golden_dir, dtype):
+    """SwinDepth encoder (depthwise-conv + BatchNorm MLP) against the reference's own
+    models/backbones/swindepth.py (tests/golden/swindepth_encoder.npz): training-mode features and gradients,
+    running statistics, eval-mode features"""
+    from medicalsemseg_amd.models.swin_unetr import SwinDepth
+    g = _load(golden_dir, "swindepth_encoder.npz")
+    vol = (24, 24, 24)
+    m = SwinDepth(vol, (2, 2, 2), 1, 32, (2, 2), (2, 4), (6, 3), drop_path_rate=0.0, compute_dtype=dtype)
+    det_fill_(m, "sd")
+    m = m.to(DEV).train()
+    x = det_tensor("sd_x", (2, 1) + vol).to(DEV)
+    feats, _ = m((x, None, None))
+    tol_f, tol_g = (1e-3, 5e-3) if dtype == torch.float32 else (6e-2, 1.5e-1)   # bf16: drift through 12 BatchNorm stages
+    loss = 0
+    for i, f in enumerate(feats):
+        got = f.permute(0, 4, 1, 2, 3)
+        assert _rel(got, g[f"out{i}"]) < tol_f, f"feature {i}: {_rel(got, g[f'out{i}']):.3e}"
+        loss = loss + (got.float() * det_tensor(f"sd_r{i}", g[f"out{i}"].shape).to(DEV)).sum()
+    loss.backward()
+    mlp = m.layers[0].blocks[1].mlp
+    # a conv bias in front of a training-mode BatchNorm has a zero gradient: rounding noise on both sides
+    assert float(mlp.dwc2.bias.grad.abs().max()) < 1e-3 * float(np.abs(g["d_dwc2_w"]).max()) and np.abs(g["d_dwc2_b"]).max() < 1e-3
+    errs = {k: _rel(t, g[k]) for k, t in (("d_dwc2_w", mlp.dwc2.weight.grad),
+                                           ("d_bn2_w", mlp.bn2.weight.grad), ("d_bn2_b", mlp.bn2.bias.grad),
+                                           ("d_fc1_w", mlp.fc1.weight.grad),
+                                           ("d_fc2_w", m.layers[1].blocks[0].mlp.fc2.weight.grad))}
+    print(f"[{dtype}] SwinDepth 24^3 gradient errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) < tol_g, errs
+    if dtype == torch.float32:
+        assert np.allclose(mlp.bn3.running_mean.cpu().numpy(), g["rm"], atol=1e-4)
+        assert np.allclose(mlp.bn3.running_var.cpu().numpy(), g["rv"], atol=1e-4)
+    m.eval()
+    with torch.no_grad():
+        fe, _ = m((x, None, None))
+    for i, f in enumerate(fe):
+        assert _rel(f.permute(0, 4, 1, 2, 3), g[f"eval{i}"]) < tol_f, f"eval feature {i}"

@@ -234,3 +234,28 @@ def test_unetrc_oracle_vs_reference_class(golden_dir):
     net.eval()
     with torch.no_grad():
         assert np.allclose(net(x).numpy(), g["logits_eval"], rtol=1e-4, atol=1e-4)
+
+
+def test_swindepth_oracle_vs_reference_file(golden_dir):
+    """oracle SwinDepth (oracle/swin.py with the depthwise-conv + BatchNorm MLP) against the reference's own
+    models/backbones/swindepth.py: training-mode features, gradients, running statistics, eval-mode features"""
+    g = _load(golden_dir, "swindepth_encoder.npz")
+    vol = (24, 24, 24)
+    m = osw.SwinTransformerNNFormer(vol, (2, 2, 2), 1, 32, (2, 2), (2, 4), (6, 3), mlp="depth")
+    det_fill_(m, "sd")
+    m.train()
+    x = det_tensor("sd_x", (2, 1) + vol).requires_grad_(True)
+    outs = m((x, None, None))
+    for i, o in enumerate(outs):
+        assert np.allclose(o.detach().numpy(), g[f"out{i}"], rtol=1e-3, atol=2e-4), i
+    sum((o * det_tensor(f"sd_r{i}", o.shape)).sum() for i, o in enumerate(outs)).backward()
+    mlp = m.layers[0].blocks[1].mlp
+    rel = lambda a, b: float(np.abs(a.detach().numpy() - b).max() / max(np.abs(b).max(), 1e-6))
+    assert rel(x.grad, g["dx"]) < 2e-3
+    assert rel(mlp.dwc2.weight.grad, g["d_dwc2_w"]) < 2e-3 and rel(mlp.bn2.weight.grad, g["d_bn2_w"]) < 2e-3
+    assert rel(mlp.fc1.weight.grad, g["d_fc1_w"]) < 2e-3
+    assert np.allclose(mlp.bn3.running_mean.numpy(), g["rm"], atol=1e-5) and np.allclose(mlp.bn3.running_var.numpy(), g["rv"], atol=1e-5)
+    m.eval()
+    with torch.no_grad():
+        for i, o in enumerate(m((x.detach(), None, None))):
+            assert np.allclose(o.numpy(), g[f"eval{i}"], rtol=1e-3, atol=2e-4), i
