@@ -45,6 +45,16 @@ WORK = {
                             "metric": "96^3 vols/sec fwd+bwd (train), Swin-UNETR-48 (MONAI / official variant)",
                             "name": "Swin-UNETR 48-feat (models/segmentors/swin_unetr_official.py: window 7, depths 2-2-2-2, heads "
                                     "3-6-12-24, Linear patch merging) 1->{c}cls, {s}^3 patches, DiceCE + AdamW, per-GPU batch {b}"},
+    # no published FLOP model; matmul + conv FLOPs of one fwd+bwd step are counted on the CPU
+    # oracle (torch.utils.flop_counter) in the cpu_baseline leg and reported as model_tflops when that leg runs
+    "segformer3d": {"gflop_per_vol": None, "gb_per_vol_bf16": None,
+                    "metric": "96^3 vols/sec fwd+bwd (train), SegFormer3D",
+                    "name": "SegFormer3D (MixVisionTransformer 48-dim, depths 2-2-2-2, heads 1-2-4-8, sr 8-4-2-1 + SegFormerHeadOfficial "
+                            "512) 1->{c}cls, {s}^3 patches, DiceCE + AdamW, per-GPU batch {b}"},
+    "swin_depth": {"gflop_per_vol": None, "gb_per_vol_bf16": None,
+                   "metric": "96^3 vols/sec fwd+bwd (train), SwinDepth-48",
+                   "name": "SwinDepth 48-feat (reference encoder swindepth: depthwise-conv + BatchNorm MLP, depths 2-2-2-2, heads "
+                           "3-6-12-24, windows 6-6-6-3, patch 2 + UNETR decoder) 1->{c}cls, {s}^3 patches, DiceCE + AdamW, per-GPU batch {b}"},
     "sliding_window": {"gflop_per_vol": 252.4e3, "gb_per_vol_bf16": 714.0,
                        "metric": "512^3 sliding-window vols/sec",
                        "name": "UNet base 1->{c}cls, {v}^3 volume, roi {s}^3, overlap 0.5, gaussian, {w} windows, sw_batch {b}"},
@@ -95,6 +105,15 @@ def cpu_baseline_train(workload, batch, size, n_cls, budget_s=25.0):
         from oracle import swin_official as O
         net = O.SwinUNETR((size,) * 3, 1, n_cls, feature_size=48)
         what = "oracle/ swin_official.SwinUNETR(48)"
+    elif workload == "segformer3d":
+        from oracle import segformer as O
+        net = O.SegFormerHeadOfficial(O.MixVisionTransformer(1, 48, (1, 2, 4, 8), (4, 4, 4, 4), True, (2, 2, 2, 2), (8, 4, 2, 1)),
+                                      [48, 96, 192, 384], n_cls, 0.1, 512)
+        what = "oracle/ segformer.SegFormerHeadOfficial(MixVisionTransformer 48)"
+    elif workload == "swin_depth":
+        from oracle import swin as O
+        net = O.SwinUNETRCustom(O.SwinTransformerNNFormer((size,) * 3, mlp="depth"), 1, n_cls, 48, 2)
+        what = "oracle/ SwinUNETRCustom(SwinDepth 48)"
     else:
         from oracle import swin as O
         net = O.SwinUNETRCustom(O.SwinTransformerNNFormer((size,) * 3), 1, n_cls, 48, 2)
@@ -103,10 +122,18 @@ def cpu_baseline_train(workload, batch, size, n_cls, budget_s=25.0):
     x, y = synth_batch(batch, size, n_cls, "cpu", 13)
     times = []
     t_all = time.perf_counter()
+    flops = None
     for i in range(4):
         t0 = time.perf_counter()
-        loss = dice_ce_loss(net((x, None, None)), y)
-        loss.backward()
+        if i == 0 and WORK[workload]["gflop_per_vol"] is None:
+            from torch.utils.flop_counter import FlopCounterMode
+            with FlopCounterMode(display=False) as fc:
+                loss = dice_ce_loss(net((x, None, None)), y)
+                loss.backward()
+            flops = fc.get_total_flops()
+        else:
+            loss = dice_ce_loss(net((x, None, None)), y)
+            loss.backward()
         opt.step()
         opt.zero_grad()
         times.append(time.perf_counter() - t0)
@@ -114,7 +141,8 @@ def cpu_baseline_train(workload, batch, size, n_cls, budget_s=25.0):
             break
     steady = times[1:] if len(times) > 1 else times
     med = sorted(steady)[len(steady) // 2]
-    return {"value": round(batch / med, 4), "unit": "vol/s", "cores": cores, "kind": "port",
+    extra = {} if flops is None else {"counted_gflop_per_vol": round(flops / batch / 1e9, 1)}
+    return {**extra, "value": round(batch / med, 4), "unit": "vol/s", "cores": cores, "kind": "port",
             "sample": f"{len(steady)} timed step(s) (after 1 warm-up) of the same B={batch} {size}^3 fwd+DiceCE+bwd+AdamW "
                       f"step, {what} fp32 on torch-CPU, median {med:.2f} s/step"}
 
@@ -266,8 +294,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU replay structure (graph A | eager gap | graph B)")
-    ap.add_argument("--workload", default="unet", choices=["unet", "swin_unetr", "swin_unetr_official", "sliding_window"],
-                    help="unet = the headline (BASELINE configs[1]); swin_unetr = configs[3]; sliding_window = configs[4]")
+    ap.add_argument("--workload", default="unet", choices=["unet", "swin_unetr", "swin_unetr_official", "sliding_window", "segformer3d", "swin_depth"],
+                    help="unet = the headline (BASELINE configs[1]); swin_unetr = configs[3]; sliding_window = configs[4]; "
+                         "segformer3d / swin_depth = the SURVEY 8(f) N3 / N4 model families")
     ap.add_argument("--sw-size", type=int, default=512)
     ap.add_argument("--sw-batch", type=int, default=8)   # windows per forward
     args = ap.parse_args()
@@ -302,6 +331,22 @@ def main():
                                       drop_path_rate=0.0, compute_dtype=dtype)
         net = SwinUNETRCustom(enc, 1, args.classes, (args.size,) * 3, 48, (2, 2, 2), compute_dtype=dtype).to(dev)
         args.no_graph = args.no_graph or bool(os.environ.get("MSSEG_SWIN_NO_GRAPH"))
+    elif args.workload == "swin_depth":
+        from medicalsemseg_amd.models.swin_unetr import SwinDepth, SwinUNETRCustom
+        enc = SwinDepth((args.size,) * 3, (2, 2, 2), 1, 48, (2, 2, 2, 2), (3, 6, 12, 24), (6, 6, 6, 3), drop_path_rate=0.0,
+                        compute_dtype=dtype)
+        net = SwinUNETRCustom(enc, 1, args.classes, (args.size,) * 3, 48, (2, 2, 2), compute_dtype=dtype).to(dev)
+        if world > 1:
+            enc.sync_batchnorm(True)      # the reference converts every BatchNorm under DDP (run_training.py:83)
+        args.no_graph = True              # BatchNorm running-statistics updates and (N > 1) collectives stay eager
+    elif args.workload == "segformer3d":
+        from medicalsemseg_amd.models.segformer3d import MixVisionTransformer, SegFormerHeadOfficial
+        enc = MixVisionTransformer(args.size, 16, 1, 48, (1, 2, 4, 8), (4, 4, 4, 4), True, 0.0, (2, 2, 2, 2), (8, 4, 2, 1),
+                                   compute_dtype=dtype)
+        net = SegFormerHeadOfficial(enc, [48, 96, 192, 384], args.classes, 0.1, 512, compute_dtype=dtype).to(dev)
+        if world > 1:
+            net.sync_group = True
+        args.no_graph = True
     elif args.workload == "swin_unetr_official":
         from medicalsemseg_amd.models.swin_unetr_official import SwinUNETR
         net = SwinUNETR((args.size,) * 3, 1, args.classes, feature_size=48, compute_dtype=dtype).to(dev)
@@ -455,11 +500,14 @@ def main():
         step_ms = dt * 1e3 / args.steps
         res["roofline"] = roofline_from_timer(hip.TIMER.summary(), args.dtype, step_ms, instr_steps,
                                               "conv3d_k3_fwd/v3" if args.workload == "unet" else None)
-        res["model_tflops"] = round(value / world * w["gflop_per_vol"] * scale / 1e3, 2)
-        res["hbm_roofline_frac_algorithmic"] = round(value / world * w["gb_per_vol_bf16"] * scale *
-                                                     (1 if args.dtype == "bf16" else 2) / HBM_PEAK_GBS, 4)
+        if w["gflop_per_vol"] is not None:
+            res["model_tflops"] = round(value / world * w["gflop_per_vol"] * scale / 1e3, 2)
+            res["hbm_roofline_frac_algorithmic"] = round(value / world * w["gb_per_vol_bf16"] * scale *
+                                                         (1 if args.dtype == "bf16" else 2) / HBM_PEAK_GBS, 4)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_train(args.workload, args.batch, args.size, args.classes)
+            if "counted_gflop_per_vol" in res["cpu_baseline"]:
+                res["model_tflops"] = round(value * res["cpu_baseline"]["counted_gflop_per_vol"] / 1e3, 2)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()

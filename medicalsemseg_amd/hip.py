@@ -37,6 +37,12 @@ SIGNATURES = {
     "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_dwconv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_dwconv3d_k3_wgrad": ([_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
+    "msseg_interp_trilinear_fwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_interp_trilinear_bwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_kv_attention_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "msseg_kv_attention_bwd_workspace_bytes": ([_i, _i, _i, _i], _sz),
+    "msseg_kv_attention_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _i, _vp], _i),
+    "msseg_scale_channels": ([_vp, _vp, _vp, _i, _ll, _i, _i, _vp], _i),
     "msseg_reduce_scratch_bytes": ([], _sz),
     "msseg_conv3d_k3_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp, _ll, _vp, _f, _f, _vp,
                                      _vp, _vp, _i, _vp, _sz, _i, _vp], _i),
@@ -590,6 +596,55 @@ def dwconv3d_k3_wgrad(x, dy, dw, dbias, acc_w=False, acc_b=False):
     sc = scratch(x.device)
     _ck(lib().msseg_dwconv3d_k3_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), _p(dbias), int(acc_w), int(acc_b), N, D, H, W, C,
                                       _p(sc), sc.numel(), dt(x), _stream()), "dwconv3d_k3_wgrad")
+
+
+def interp_trilinear(x, y):
+    """y = F.interpolate(x, size=y.shape[1:4], mode='trilinear', align_corners=False), both channels-last"""
+    _need_gpu(x, y)
+    N, ID, IH, IW, C = x.shape
+    _ck(lib().msseg_interp_trilinear_fwd(_p(x), ld(x), _p(y), ld(y), N, ID, IH, IW, y.shape[1], y.shape[2], y.shape[3], C,
+                                         dt(x), _stream()), "interp_trilinear_fwd")
+    return y
+
+
+def interp_trilinear_bwd(dy, dx):
+    _need_gpu(dy, dx)
+    N, ID, IH, IW, C = dx.shape
+    _ck(lib().msseg_interp_trilinear_bwd(_p(dy), ld(dy), _p(dx), ld(dx), N, ID, IH, IW, dy.shape[1], dy.shape[2], dy.shape[3],
+                                         C, dt(dx), _stream()), "interp_trilinear_bwd")
+    return dx
+
+
+def kv_attention_fwd(q, kv, heads, scale):
+    """q [B, N, C], kv [B, M, 2C] -> (o [B, N, C], lse [B, heads, N])"""
+    _need_gpu(q, kv)
+    B, N, C = q.shape
+    M = kv.shape[1]
+    o = torch.empty_like(q)
+    lse = torch.empty(B, heads, N, dtype=torch.float32, device=q.device)
+    _ck(lib().msseg_kv_attention_fwd(_p(q), _p(kv), _p(o), _p(lse), B, N, M, heads, C // heads, scale, dt(q), _stream()),
+        "kv_attention_fwd")
+    return o, lse
+
+
+def kv_attention_bwd(q, kv, o, lse, dout, heads, scale):
+    _need_gpu(q, kv, o, lse, dout)
+    B, N, C = q.shape
+    M = kv.shape[1]
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    nb = lib().msseg_kv_attention_bwd_workspace_bytes(B, N, M, heads)
+    ws = torch.empty(nb, dtype=torch.uint8, device=q.device)
+    _ck(lib().msseg_kv_attention_bwd(_p(q), _p(kv), _p(o), _p(lse), _p(dout), _p(dq), _p(dkv), B, N, M, heads, C // heads,
+                                     scale, _p(ws), nb, dt(q), _stream()), "kv_attention_bwd")
+    return dq, dkv
+
+
+def scale_channels(x, scale, y):
+    """y[n, ..., c] = x[n, ..., c] * scale[n, c] (fp32 scale)"""
+    _need_gpu(x, scale, y)
+    N, C = x.shape[0], x.shape[-1]
+    _ck(lib().msseg_scale_channels(_p(x), _p(scale), _p(y), N, x.numel() // (N * C), C, dt(x), _stream()), "scale_channels")
+    return y
 
 
 def channel_stats(x, stats=None):

@@ -7,6 +7,7 @@ for the models on the hot path.
   at ``model_builder.py:15-66``.
 * ``cfg.model == 'SwinDepth'`` -- the same wiring around the ``SwinDepth`` encoder (depthwise-conv + BatchNorm MLP), the
   branch at ``model_builder.py:120-171``.
+* ``cfg.model == 'SegFormer3D'`` -- ``MixVisionTransformer`` + ``SegFormerHeadOfficial`` (``model_builder.py:190-205``).
 * ``cfg.model == 'SwinUNETR'`` -- the vendored MONAI variant of ``models/segmentors/swin_unetr_official.py`` (window 7,
   ``feature_size = cfg.hidden_dim``), the literal "Swin-UNETR 48-feat" of BASELINE.json configs[3] (the reference keeps
   the class but wires no ``build_model`` branch to it).
@@ -19,7 +20,7 @@ import torch
 
 from .unet import UNET_FEATURES, UNet
 
-OUT_OF_SCOPE = ("SwInception", "SwinSegFormer", "SegFormer3D", "GCViTUNETR", "FocalNetUNETR")
+OUT_OF_SCOPE = ("SwInception", "SwinSegFormer", "GCViTUNETR", "FocalNetUNETR")
 
 
 def _dtype(cfg):
@@ -53,11 +54,18 @@ def build_model(cfg):
         return SwinUNETRCustom(encoder, in_channels=cfg.in_chans, out_channels=cfg.output_dim,
                                img_size=_t3(cfg.vol_size), hidden_size=cfg.hidden_dim, patch_size=_t3(cfg.patch_size),
                                compute_dtype=_dtype(cfg))
+    if name == "SegFormer3D":                                   # model_builder.py:190-205
+        from .segformer3d import MixVisionTransformer, SegFormerHeadOfficial
+        enc = MixVisionTransformer(img_size=cfg.vol_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans,
+                                   embed_dim=cfg.hidden_dim, depths=tuple(cfg.depths), num_heads=tuple(cfg.num_heads),
+                                   sr_ratios=(8, 4, 2, 1), qkv_bias=cfg.qkv_bias, compute_dtype=_dtype(cfg))
+        return SegFormerHeadOfficial(enc, [cfg.hidden_dim * 2 ** i for i in range(len(cfg.depths))], cfg.output_dim,
+                                     compute_dtype=_dtype(cfg))
     if name == "SwinUNETR":
         from .swin_unetr_official import SwinUNETR
         return SwinUNETR(_t3(cfg.vol_size), cfg.in_chans, cfg.output_dim, depths=tuple(cfg.depths),
                          num_heads=tuple(cfg.num_heads), feature_size=cfg.hidden_dim, compute_dtype=_dtype(cfg))
     if name in OUT_OF_SCOPE:
         raise NotImplementedError(f"model '{name}' is a research variant outside this build's hot-path scope "
-                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR', 'SwinDepth', 'SwinUNETR']")
+                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR', 'SwinDepth', 'SegFormer3D', 'SwinUNETR']")
     raise ValueError(f"unknown cfg.model '{name}'")

@@ -37,9 +37,9 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x = _c(x)
-        cout, cin = weight.shape
+        cout, cin = weight.shape[:2]           # nn.Linear weight, or a 1x1x1 conv weight [cout, cin, 1, 1, 1]
         T = x.dtype
-        wp = _packed(weight, T, "f", lambda: hip.pack_conv_k1(weight.detach().contiguous(), T))
+        wp = _packed(weight, T, "f", lambda: hip.pack_conv_k1(weight.detach().reshape(cout, cin), T))
         y = torch.empty(x.shape[:-1] + (cout,), dtype=T, device=x.device)
         hip.conv3d_k1(x, wp, bias, y, cin, cout)
         ctx.save_for_backward(x)
@@ -51,16 +51,16 @@ class LinearFn(torch.autograd.Function):
         x, = ctx.saved_tensors
         weight, bias = ctx.weight, ctx.bias
         dy = _c(dy)
-        cout, cin = weight.shape
+        cout, cin = weight.shape[:2]
         T = x.dtype
         dx = None
         if ctx.needs_input_grad[0]:
-            wpd = _packed(weight, T, "d", lambda: hip.pack_conv_k1(weight.detach().contiguous(), T, dgrad=True))
+            wpd = _packed(weight, T, "d", lambda: hip.pack_conv_k1(weight.detach().reshape(cout, cin), T, dgrad=True))
             dx = torch.empty_like(x)
             hip.conv3d_k1(dy, wpd, None, dx, cout, cin)
         if ctx.needs_input_grad[1]:
             g, acc = _gbuf(weight)
-            hip.conv3d_k1_wgrad(x, dy, g, cin, cout, acc)
+            hip.conv3d_k1_wgrad(x, dy, g.view(cout, cin), cin, cout, acc)
         if bias is not None and ctx.needs_input_grad[2]:
             g, acc = _gbuf(bias)
             hip.channel_sum(dy, g, acc)
@@ -214,20 +214,25 @@ class Conv3Fn(torch.autograd.Function):
 
 
 class PatchConvFn(torch.autograd.Function):
-    """Conv3d with kernel = stride = k, no padding, few input channels (PatchEmbed3D.proj)"""
+    """Conv3d through the im2col-style gather kernel: kernel k, stride s (default k), padding p.  Used for patch
+    embeddings (few input channels: PatchEmbed3D.proj k = s = 2, SegFormer's OverlapPatchEmbed k7 s4 p3) and for the
+    spatial-reduction conv of SegFormer's attention (k = s, many channels), whose input gradient is a flat GEMM on the
+    [Cout, Cin k^3] view of the weight followed by a depth-to-space permute."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, k):
+    def forward(ctx, x, weight, bias, k, s=None, p=0):
         x = _c(x)
+        s = k if s is None else s
         cout, cin = weight.shape[0], weight.shape[1]
         T = x.dtype
         B, D, H, W, _ = x.shape
         wp = _packed(weight, T, "g", lambda: hip.pack_conv_gather(weight.detach().contiguous(), T))
-        y = torch.empty(B, D // k, H // k, W // k, cout, dtype=T, device=x.device)
-        hip.conv3d_gather(x, wp, bias, y, cin, cout, k, k, 0)
+        od, oh, ow = ((v + 2 * p - k) // s + 1 for v in (D, H, W))
+        y = torch.empty(B, od, oh, ow, cout, dtype=T, device=x.device)
+        hip.conv3d_gather(x, wp, bias, y, cin, cout, k, s, p)
         ctx.save_for_backward(x)
         ctx.weight, ctx.bias = weight, bias
-        ctx.k = k
+        ctx.k, ctx.s, ctx.p = k, s, p
         return y
 
     @staticmethod
@@ -236,15 +241,25 @@ class PatchConvFn(torch.autograd.Function):
         weight, bias = ctx.weight, ctx.bias
         dy = _c(dy)
         cout, cin = weight.shape[0], weight.shape[1]
+        k = ctx.k
         if ctx.needs_input_grad[1]:
             g, acc = _gbuf(weight)
-            hip.conv3d_gather_wgrad(x, dy, g, cin, cout, ctx.k, ctx.k, 0, acc)
+            hip.conv3d_gather_wgrad(x, dy, g, cin, cout, k, ctx.s, ctx.p, acc)
         if bias is not None and ctx.needs_input_grad[2]:
             g, acc = _gbuf(bias)
             hip.channel_sum(dy, g, acc)
+        dx = None
         if ctx.needs_input_grad[0]:
-            raise NotImplementedError("gradient w.r.t. the input volume is not needed on this path")
-        return None, None, None, None
+            B, D, H, W, _ = x.shape
+            if ctx.s != k or ctx.p != 0 or D % k or H % k or W % k:
+                raise NotImplementedError("input gradient of a gather conv needs kernel == stride, no padding")
+            T = x.dtype
+            K = cin * k ** 3
+            wpd = _packed(weight, T, "gd", lambda: hip.pack_conv_k1(weight.detach().reshape(cout, K), T, dgrad=True))
+            dxs = torch.empty(dy.shape[:-1] + (K,), dtype=T, device=x.device)          # [B, d, h, w, (ci, kd, kh, kw)]
+            hip.conv3d_k1(dy, wpd, None, dxs, cout, K)
+            dx = dxs.view(B, D // k, H // k, W // k, cin, k, k, k).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(B, D, H, W, cin)
+        return dx, None, None, None, None, None
 
 
 class DwConv3Fn(torch.autograd.Function):
@@ -291,6 +306,111 @@ class BatchNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, stats = ctx.saved_tensors
         return ctx.op.bwd(x, stats, _c(dy)), None, None, None, None
+
+
+class InterpFn(torch.autograd.Function):
+    """F.interpolate(mode='trilinear', align_corners=False) on a channels-last volume"""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        x = _c(x)
+        ctx.in_shape = x.shape
+        y = torch.empty((x.shape[0],) + tuple(size) + (x.shape[-1],), dtype=x.dtype, device=x.device)
+        return hip.interp_trilinear(x, y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(ctx.in_shape, dtype=dy.dtype, device=dy.device)
+        return hip.interp_trilinear_bwd(_c(dy), dx), None
+
+
+class UpsampleConcatFn(torch.autograd.Function):
+    """cat([interpolate(t, size) for t in tensors], channel) with every piece written straight into its channel slice of
+    the result (SegFormer head, /root/reference/models/segmentors/segformer_head_official.py:72-84); a tensor that
+    already has the target size is copied by the same kernel (all interpolation weights are 0 / 1)."""
+
+    @staticmethod
+    def forward(ctx, size, *tensors):
+        ts = [_c(t) for t in tensors]
+        B, T, dev = ts[0].shape[0], ts[0].dtype, ts[0].device
+        chans = [t.shape[-1] for t in ts]
+        cat = torch.empty((B,) + tuple(size) + (sum(chans),), dtype=T, device=dev)
+        off = 0
+        for t, c in zip(ts, chans):
+            hip.interp_trilinear(t, cat[..., off:off + c])
+            off += c
+        ctx.shapes, ctx.chans = [t.shape for t in ts], chans
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        dcat = _c(dcat)
+        grads, off = [], 0
+        for shp, c, need in zip(ctx.shapes, ctx.chans, ctx.needs_input_grad[1:]):
+            g = None
+            if need:
+                g = torch.empty(shp, dtype=dcat.dtype, device=dcat.device)
+                hip.interp_trilinear_bwd(dcat[..., off:off + c], g)
+            grads.append(g)
+            off += c
+        return (None, *grads)
+
+
+class KvAttnFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v with the keys / values of a spatially reduced token set (SegFormer's attention,
+    /root/reference/models/backbones/segformer_backbone.py:96-117): q [B, N, C], kv [B, M, 2C] -> [B, N, C]"""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads):
+        q, kv = _c(q), _c(kv)
+        scale = float(q.shape[-1] // heads) ** -0.5
+        o, lse = hip.kv_attention_fwd(q, kv, heads, scale)
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.heads, ctx.scale = heads, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse = ctx.saved_tensors
+        dq, dkv = hip.kv_attention_bwd(q, kv, o, lse, _c(do), ctx.heads, ctx.scale)
+        return dq, dkv, None
+
+
+class ScaleChannelsFn(torch.autograd.Function):
+    """x * scale[n, c]: nn.Dropout3d with the keep mask / (1 - p) given as `scale` (fp32 [B, C])"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _c(x)
+        ctx.save_for_backward(scale)
+        return hip.scale_channels(x, scale, torch.empty_like(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        scale, = ctx.saved_tensors
+        dy = _c(dy)
+        return hip.scale_channels(dy, scale, torch.empty_like(dy)), None
+
+
+def interp_trilinear(x, size):
+    return InterpFn.apply(x, tuple(size))
+
+
+def upsample_concat(size, tensors):
+    return UpsampleConcatFn.apply(tuple(size), *tensors)
+
+
+def kv_attention(q, kv, heads):
+    return KvAttnFn.apply(q, kv, heads)
+
+
+def dropout3d(x, p, training, mask=None):
+    """channel dropout; `mask` (fp32 [B, C] of 0 / 1) overrides the Bernoulli draw"""
+    if not training or p == 0.0:
+        return x
+    if mask is None:
+        mask = torch.empty(x.shape[0], x.shape[-1], device=x.device, dtype=torch.float32).bernoulli_(1.0 - p)
+    return ScaleChannelsFn.apply(x, (mask.to(x.device, torch.float32) / (1.0 - p)).contiguous())
 
 
 def dwconv3(x, weight, bias=None):

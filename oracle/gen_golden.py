@@ -25,7 +25,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 sys.path.insert(0, REPO)
-from tests.golden_util import (SW_CASES, UNETRC_PROBES, ToyTokenEncoder, det_fill_, det_tensor, probe,  # noqa: E402
+from tests.golden_util import (SEGFORMER_CFG, SW_CASES, UNETRC_PROBES, ToyTokenEncoder, det_fill_, det_tensor, probe,  # noqa: E402
                                sw_predictor)
 
 
@@ -175,6 +175,40 @@ def gen_swindepth():
         for i, o in enumerate(m((x.detach(), None, None))):
             out[f"eval{i}"] = o
     _save("swindepth_encoder.npz", **out)
+
+
+def gen_segformer3d():
+    """the reference's SegFormer3D (models/backbones/segformer_backbone.py MixVisionTransformer + models/segmentors/
+    segformer_head_official.py SegFormerHeadOfficial, wired as model_builder.py:190-205) in TRAINING mode (BatchNorm batch
+    statistics; dropout 0 and stochastic depth 0 so that the pass is deterministic): logits, encoder features, gradients;
+    then the eval-mode logits on the updated running statistics"""
+    import models.backbones.segformer_backbone as SB
+    import models.segmentors.segformer_head_official as SH
+    c = SEGFORMER_CFG
+    enc = SB.MixVisionTransformer(img_size=c["vol"], patch_size=16, in_chans=1, embed_dim=c["embed_dim"], depths=c["depths"],
+                                  num_heads=c["num_heads"], sr_ratios=[8, 4, 2, 1], qkv_bias=True)
+    net = SH.SegFormerHeadOfficial(encoder=enc, in_channels=[c["embed_dim"] * 2 ** i for i in range(4)],
+                                   num_classes=c["classes"], dropout_ratio=0.0, embedding_dim=c["embedding_dim"])
+    det_fill_(net, "segf.")
+    net.train()
+    x = det_tensor("segf_x", (2, 1) + c["vol"])
+    feats = enc((x, None, None))
+    y = net((x, None, None))
+    (y * det_tensor("segf_r", tuple(y.shape))).sum().backward()
+    P = dict(net.named_parameters())
+    keys = ["encoder.patch_embed1.proj.weight", "encoder.block1.0.attn.q.weight", "encoder.block1.0.attn.kv.weight",
+            "encoder.block1.0.attn.sr.weight", "encoder.block1.1.mlp.dwconv.dwconv.weight", "encoder.block2.0.attn.sr.bias",
+            "encoder.block4.0.attn.kv.bias", "encoder.patch_embed3.proj.weight", "encoder.norm2.weight",
+            "linear_c4.proj.weight", "linear_c1.proj.bias", "linear_fuse.conv.weight", "linear_fuse.bn.weight",
+            "linear_pred.weight", "linear_pred.bias"]
+    sub = lambda t: t[:, :, ::2, ::2, ::2].contiguous()        # fixtures stay small: every second voxel per axis
+    out = dict(logits_s2=sub(y), feat1_s2=sub(feats[1]), feat2=feats[2], feat3=feats[3], feat4=feats[4],
+               **{"g:" + k: probe(P[k].grad) for k in keys})
+    out["rm"], out["rv"] = net.linear_fuse.bn.running_mean, net.linear_fuse.bn.running_var
+    net.eval()
+    with torch.no_grad():
+        out["logits_eval_s2"] = sub(net((x, None, None)))
+    _save("segformer3d_ref.npz", **out)
 
 
 def gen_lr_and_misc():
@@ -389,6 +423,7 @@ def main():
     gen_basic_layer_mask(ref)
     gen_encoder(ref)
     gen_swindepth()
+    gen_segformer3d()
     gen_lr_and_misc()
     gen_unetr_conv_blocks()
     gen_unetrc()

@@ -89,3 +89,7 @@ UNETRC_PROBES = ["decoder0.0.block.0.block.weight", "decoder0.0.block.1.weight",
 def probe(t, n=4096):
     """the first n elements of a (large) gradient: what the UNETRC fixtures keep of it"""
     return t.detach().reshape(-1)[:n].clone()
+
+
+# the SegFormer3D fixture (tests/golden/segformer3d_ref.npz): MixVisionTransformer + SegFormerHeadOfficial, qkv_bias on
+SEGFORMER_CFG = dict(vol=(64, 64, 64), embed_dim=32, depths=[2, 1, 1, 1], num_heads=[1, 2, 4, 8], classes=3, embedding_dim=64)

@@ -884,3 +884,73 @@ def test_dwconv3_vs_torch(dtype, C, sp):
     y2 = ops.dwconv3(xg, wp, bp)
     y2.backward(cl(r, dtype, dev))
     assert torch.equal(wp.grad, 2 * g1)          # accumulate path; fixed-order sums -> bit-identical second pass
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("isz,osz", [((2, 2, 2), (16, 16, 16)), ((4, 4, 4), (16, 16, 16)), ((16, 16, 16), (64, 64, 64)),
+                                     ((3, 5, 4), (7, 9, 6)), ((8, 8, 8), (8, 8, 8)), ((9, 6, 10), (4, 3, 5))])
+def test_interp_trilinear_vs_torch(dtype, isz, osz):
+    """F.interpolate(mode='trilinear', align_corners=False) and its adjoint (gather form, deterministic): up, down,
+    identity, odd sizes; output / gradient as channel slices of wider buffers"""
+    from medicalsemseg_amd import hip
+    dev = _dev()
+    N, C = 2, 16
+    x = gen(N, C, *isz, seed=41)
+    r = gen(N, C, *osz, seed=42)
+    xr, rr = rnd(dtype, x, r)
+    xr = xr.clone().requires_grad_(True)
+    yref = F.interpolate(xr, size=osz, mode="trilinear", align_corners=False)
+    yref.backward(rr)
+    big = torch.zeros(N, *osz, 3 * C, dtype=dtype, device=dev)
+    hip.interp_trilinear(cl(x, dtype, dev), big[..., C:2 * C])
+    check(ncdhw(big[..., C:2 * C]), yref.detach(), dtype, "trilinear fwd")
+    assert float(big[..., :C].float().abs().max()) == 0 and float(big[..., 2 * C:].float().abs().max()) == 0
+    gbig = torch.zeros(N, *osz, 2 * C, dtype=dtype, device=dev)
+    gbig[..., C:] = cl(r, dtype, dev)
+    dx = torch.empty(N, *isz, C, dtype=dtype, device=dev)
+    hip.interp_trilinear_bwd(gbig[..., C:], dx)
+    check(ncdhw(dx), xr.grad, dtype, "trilinear bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,M,heads,hd", [(4096, 8, 1, 32), (512, 27, 2, 48), (216, 27, 4, 48), (27, 27, 8, 48),
+                                          (300, 70, 2, 16), (64, 130, 1, 64)])
+def test_kv_attention_vs_torch(dtype, N, M, heads, hd):
+    """softmax(q k^T / sqrt(hd)) v with a small key set (SegFormer's spatial-reduction attention): forward, dq, dk, dv vs
+    the reference's formulation in torch (segformer_backbone.py:96-117); more than one 64-key LDS tile included"""
+    from medicalsemseg_amd import ops
+    dev = _dev()
+    B, C = 2, heads * hd
+    q = gen(B, N, C, seed=51)
+    kv = gen(B, M, 2 * C, seed=52)
+    r = gen(B, N, C, seed=53)
+    qr, kvr, rr = rnd(dtype, q, kv, r)
+    qr = qr.clone().requires_grad_(True); kvr = kvr.clone().requires_grad_(True)
+    qh = qr.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
+    kvh = kvr.reshape(B, M, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    attn = ((qh @ kvh[0].transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    yref = (attn @ kvh[1]).transpose(1, 2).reshape(B, N, C)
+    yref.backward(rr)
+    qg = q.to(dev, dtype).requires_grad_(True); kvg = kv.to(dev, dtype).requires_grad_(True)
+    y = ops.kv_attention(qg, kvg, heads)
+    check(y, yref.detach(), dtype, "kv attention fwd")
+    y.backward(r.to(dev, dtype))
+    check(qg.grad, qr.grad, dtype, "kv attention dq")
+    check(kvg.grad, kvr.grad, dtype, "kv attention dkv", scale=float(kvr.grad.abs().max()))
+    g1 = kvg.grad.clone()
+    kvg.grad = None; qg.grad = None
+    ops.kv_attention(qg, kvg, heads).backward(r.to(dev, dtype))
+    assert torch.equal(kvg.grad, g1)                       # fixed-order sums: bit-reproducible
+
+
+def test_dropout3d_with_given_mask():
+    from medicalsemseg_amd import ops
+    dev = _dev()
+    x = gen(3, 4, 5, 6, 16, seed=61).to(dev).requires_grad_(True)
+    mask = (gen(3, 16, seed=62) > 0).float()
+    y = ops.dropout3d(x, 0.25, True, mask)
+    want = x.detach() * (mask / 0.75).to(dev).view(3, 1, 1, 1, 16)
+    assert torch.allclose(y, want, rtol=1e-6, atol=1e-7)
+    y.sum().backward()
+    assert torch.allclose(x.grad, (mask / 0.75).to(dev).view(3, 1, 1, 1, 16).expand_as(x), rtol=1e-6)
+    assert ops.dropout3d(x, 0.25, False) is x

@@ -254,3 +254,24 @@ def test_unetrc_state_dict_keys_equal_reference_layout():
     sa, sb = a.state_dict(), b.state_dict()
     assert list(sa) == list(sb)
     assert all(sa[k].shape == sb[k].shape for k in sa)
+
+
+def test_segformer3d_and_swindepth_state_dict_keys_and_builder():
+    """product SegFormer3D / SwinDepth keep the reference's key layout (their oracles are pinned against the reference files,
+    weights filled by key name) and build_model wires the branches of model_builder.py:120-171,190-205"""
+    import argparse
+    from medicalsemseg_amd.models.model_builder import build_model
+    from oracle import segformer as OS, swin as OW
+    cfg = argparse.Namespace(model="SegFormer3D", vol_size=64, patch_size=16, in_chans=1, hidden_dim=32, depths=[2, 1, 1, 1],
+                             num_heads=[1, 2, 4, 8], qkv_bias=True, output_dim=3, compute_dtype="f32")
+    net = build_model(cfg)
+    ref = OS.SegFormerHeadOfficial(OS.MixVisionTransformer(1, 32, (1, 2, 4, 8), (4, 4, 4, 4), True, (2, 1, 1, 1), (8, 4, 2, 1)),
+                                   [32, 64, 128, 256], 3, 0.1, 512)
+    assert sorted(net.state_dict()) == sorted(ref.state_dict())
+    assert all(net.state_dict()[k].shape == v.shape for k, v in ref.state_dict().items())
+    cfg = argparse.Namespace(model="SwinDepth", vol_size=(24, 24, 24), patch_size=(2, 2, 2), in_chans=1, hidden_dim=32,
+                             depths=[2, 2], num_heads=[2, 4], window_size=[6, 3], qkv_bias=True, mlp_ratio=4.0, output_dim=2,
+                             compute_dtype="bf16")
+    net = build_model(cfg)
+    enc = OW.SwinTransformerNNFormer((24, 24, 24), (2, 2, 2), 1, 32, (2, 2), (2, 4), (6, 3), mlp="depth")
+    assert sorted(net.encoder.state_dict()) == sorted(enc.state_dict())

@@ -259,3 +259,35 @@ def test_swindepth_oracle_vs_reference_file(golden_dir):
     with torch.no_grad():
         for i, o in enumerate(m((x.detach(), None, None))):
             assert np.allclose(o.numpy(), g[f"eval{i}"], rtol=1e-3, atol=2e-4), i
+
+
+def test_segformer3d_oracle_vs_reference_files(golden_dir):
+    """oracle/segformer.py against the reference's own MixVisionTransformer + SegFormerHeadOfficial (training-mode logits,
+    encoder features, gradient probes, BatchNorm running statistics, eval-mode logits)"""
+    from oracle import segformer as OS
+    from tests.golden_util import SEGFORMER_CFG as c, probe
+    g = _load(golden_dir, "segformer3d_ref.npz")
+    torch.set_num_threads(8)
+    enc = OS.MixVisionTransformer(1, c["embed_dim"], c["num_heads"], (4, 4, 4, 4), True, c["depths"], (8, 4, 2, 1))
+    net = OS.SegFormerHeadOfficial(enc, [c["embed_dim"] * 2 ** i for i in range(4)], c["classes"], 0.0, c["embedding_dim"])
+    det_fill_(net, "segf.")
+    net.train()
+    x = det_tensor("segf_x", (2, 1) + c["vol"])
+    sub = lambda t: t[:, :, ::2, ::2, ::2]
+    feats = enc((x, None, None))
+    assert np.allclose(sub(feats[1]).detach().numpy(), g["feat1_s2"], rtol=1e-3, atol=1e-4)
+    for i in (2, 3, 4):
+        assert np.allclose(feats[i].detach().numpy(), g[f"feat{i}"], rtol=1e-3, atol=1e-4), i
+    y = net((x, None, None))
+    assert np.allclose(sub(y).detach().numpy(), g["logits_s2"], rtol=1e-3, atol=1e-4)
+    (y * det_tensor("segf_r", tuple(y.shape))).sum().backward()
+    P = dict(net.named_parameters())
+    for k in [k[2:] for k in g.files if k.startswith("g:")]:
+        want = g["g:" + k]
+        got = probe(P[k].grad).numpy()
+        assert np.abs(got - want).max() <= 2e-3 * max(np.abs(want).max(), 1e-3), k
+    assert np.allclose(net.linear_fuse.bn.running_mean.numpy(), g["rm"], atol=1e-5)
+    assert np.allclose(net.linear_fuse.bn.running_var.numpy(), g["rv"], atol=1e-5)
+    net.eval()
+    with torch.no_grad():
+        assert np.allclose(sub(net((x, None, None))).numpy(), g["logits_eval_s2"], rtol=1e-3, atol=1e-4)
