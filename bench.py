@@ -338,7 +338,7 @@ def main():
         net = SwinUNETRCustom(enc, 1, args.classes, (args.size,) * 3, 48, (2, 2, 2), compute_dtype=dtype).to(dev)
         if world > 1:
             enc.sync_batchnorm(True)      # the reference converts every BatchNorm under DDP (run_training.py:83)
-        args.no_graph = True              # BatchNorm running-statistics updates and (N > 1) collectives stay eager
+        args.no_graph = args.no_graph or world > 1    # SyncBatchNorm's collectives (and their host-side count) stay eager
     elif args.workload == "segformer3d":
         from medicalsemseg_amd.models.segformer3d import MixVisionTransformer, SegFormerHeadOfficial
         enc = MixVisionTransformer(args.size, 16, 1, 48, (1, 2, 4, 8), (4, 4, 4, 4), True, 0.0, (2, 2, 2, 2), (8, 4, 2, 1),
@@ -346,7 +346,7 @@ def main():
         net = SegFormerHeadOfficial(enc, [48, 96, 192, 384], args.classes, 0.1, 512, compute_dtype=dtype).to(dev)
         if world > 1:
             net.sync_group = True
-        args.no_graph = True
+        args.no_graph = args.no_graph or world > 1
     elif args.workload == "swin_unetr_official":
         from medicalsemseg_amd.models.swin_unetr_official import SwinUNETR
         net = SwinUNETR((args.size,) * 3, 1, args.classes, feature_size=48, compute_dtype=dtype).to(dev)

@@ -216,20 +216,22 @@ int msseg_dwconv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long l
  * SegFormer3D pieces (models/backbones/segformer_backbone.py:51-117, models/segmentors/segformer_head_official.py:65-90).
  * interp_trilinear: F.interpolate(mode='trilinear', align_corners=False) between channels-last volumes
  *   x [N, ID, IH, IW, C] and y [N, OD, OH, OW, C] (C % (16 / sizeof(elem)) == 0); bwd = its adjoint in gather form
- *   (deterministic): dx from dy.
+ *   (deterministic, one axis per pass, fp32 intermediates in `workspace`): dx from dy; C % 4 == 0 suffices here.
  * kv_attention: o = softmax(q k^T * scale) v per head with few keys (the spatial-reduction attention): q, o [B, N, C],
  *   kv [B, M, 2C] (k = first C channels, v = last C; channel = head * head_dim + c), head_dim in {16, 32, 48, 64};
  *   lse [B, heads, N] fp32 (log-sum-exp of the scaled scores, kept for the backward).  bwd: dq [B, N, C] and
- *   dkv [B, M, 2C] (both fully written); workspace of msseg_kv_attention_bwd_workspace_bytes() holds P and dS.
+ *   dkv [B, M, 2C] (both fully written); workspace of msseg_kv_attention_bwd_workspace_bytes() holds P, dS and the
+ *   per-query-chunk partial sums of dk / dv.
  * scale_channels: y[n, v, c] = x[n, v, c] * scale[n][c] (Dropout3d with a given mask / (1 - p)); dense [N, S, C].
  * ------------------------------------------------------------------------------------------- */
 int msseg_interp_trilinear_fwd(const void* x, long long ldx, void* y, long long ldy, int N, int ID, int IH, int IW, int OD,
                                int OH, int OW, int C, int dtype, msseg_stream_t stream);
+size_t msseg_interp_trilinear_bwd_workspace_bytes(int N, int ID, int IH, int IW, int OD, int OH, int OW, int C);
 int msseg_interp_trilinear_bwd(const void* dy, long long lddy, void* dx, long long lddx, int N, int ID, int IH, int IW, int OD,
-                               int OH, int OW, int C, int dtype, msseg_stream_t stream);
+                               int OH, int OW, int C, void* workspace, size_t workspace_bytes, int dtype, msseg_stream_t stream);
 int msseg_kv_attention_fwd(const void* q, const void* kv, void* o, float* lse, int B, int N, int M, int heads, int head_dim,
                            float scale, int dtype, msseg_stream_t stream);
-size_t msseg_kv_attention_bwd_workspace_bytes(int B, int N, int M, int heads);
+size_t msseg_kv_attention_bwd_workspace_bytes(int B, int N, int M, int heads, int head_dim);
 int msseg_kv_attention_bwd(const void* q, const void* kv, const void* o, const float* lse, const void* dout, void* dq, void* dkv,
                            int B, int N, int M, int heads, int head_dim, float scale, void* workspace, size_t workspace_bytes,
                            int dtype, msseg_stream_t stream);

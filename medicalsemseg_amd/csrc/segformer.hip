@@ -107,45 +107,57 @@ MSSEG_DEVFN void range_of(int i, float scale, int out, int* lo, int* hi) {
     *hi = b > out - 1 ? out - 1 : b;
 }
 
-// dx[n, i] = sum over outputs o of w(o, i) * dy[n, o]   (x = the low-resolution side; p.x = dx, p.y = dy)
-template <typename T>
-__global__ __launch_bounds__(256) void interp_bwd_kernel(const InterpParams p) {
-    constexpr int E = Ch<T>::E;
-    const int nch = p.C / E;
-    const long long total = (long long)p.N * p.ID * p.IH * p.IW * nch;
-    T* __restrict__ dxg = (T*)p.x;
-    const T* __restrict__ dyg = (const T*)p.y;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int ch = (int)(i % nch);
-        long long v = i / nch;
-        const int iw = (int)(v % p.IW); long long t = v / p.IW;
-        const int ih = (int)(t % p.IH); t /= p.IH;
-        const int id = (int)(t % p.ID); const int n = (int)(t / p.ID);
-        int d0, d1, h0, h1, w0, w1;
-        range_of(id, p.sd, p.OD, &d0, &d1);
-        range_of(ih, p.sh, p.OH, &h0, &h1);
-        range_of(iw, p.sw, p.OW, &w0, &w1);
-        float acc[E];
+// Adjoint of the interpolation, one axis at a time (trilinear weights are a product of three 1-D weights, so the adjoint is
+// the composition of three 1-D adjoints): dx[outer, i, inner] = sum over outputs o of w(o, i) * dy[outer, o, inner].
+// Gather form -- every input index collects the outputs that read it -- hence deterministic.  Four channels per thread;
+// intermediates are fp32.
+struct Interp1Params {
+    const void* dy; long long lddy;    // [outer, Lo, inner, C] rows of lddy elements
+    void* dx; long long lddx;          // [outer, Li, inner, C]
+    long long outer, inner;
+    int Lo, Li, C;
+    float scale;                       // Li / Lo
+};
+
+template <typename T> MSSEG_DEVFN void ld4(const T* p, float* f);
+template <> MSSEG_DEVFN void ld4<float>(const float* p, float* f) {
+    const f32x4_t v = *(const f32x4_t*)p;
+    f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+}
+template <> MSSEG_DEVFN void ld4<bf16_t>(const bf16_t* p, float* f) {
+    const bf16x4_t v = *(const bf16x4_t*)p;
+    f[0] = (float)v[0]; f[1] = (float)v[1]; f[2] = (float)v[2]; f[3] = (float)v[3];
+}
+template <typename T> MSSEG_DEVFN void st4(T* p, const float* f);
+template <> MSSEG_DEVFN void st4<float>(float* p, const float* f) { *(f32x4_t*)p = f32x4_t{f[0], f[1], f[2], f[3]}; }
+template <> MSSEG_DEVFN void st4<bf16_t>(bf16_t* p, const float* f) {
+    *(bf16x4_t*)p = bf16x4_t{(bf16_t)f[0], (bf16_t)f[1], (bf16_t)f[2], (bf16_t)f[3]};
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void interp1_bwd_kernel(const Interp1Params p) {
+    const int nch = p.C / 4;
+    const long long total = p.outer * p.Li * p.inner * nch;
+    const TI* __restrict__ gy = (const TI*)p.dy;
+    TO* __restrict__ gx = (TO*)p.dx;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int ch = (int)(t % nch);
+        long long v = t / nch;
+        const long long in = v % p.inner; v /= p.inner;
+        const int i = (int)(v % p.Li);
+        const long long ou = v / p.Li;
+        int lo, hi;
+        range_of(i, p.scale, p.Lo, &lo, &hi);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int o = lo; o <= hi; ++o) {
+            const float wt = wt_of(o, i, p.scale, p.Li);
+            if (wt == 0.f) continue;
+            float g[4];
+            ld4<TI>(gy + ((ou * p.Lo + o) * p.inner + in) * p.lddy + ch * 4, g);
 #pragma unroll
-        for (int e = 0; e < E; ++e) acc[e] = 0.f;
-        for (int od = d0; od <= d1; ++od) {
-            const float wd = wt_of(od, id, p.sd, p.ID);
-            if (wd == 0.f) continue;
-            for (int oh = h0; oh <= h1; ++oh) {
-                const float wh = wd * wt_of(oh, ih, p.sh, p.IH);
-                if (wh == 0.f) continue;
-                const T* row = dyg + (((long long)n * p.OD + od) * p.OH + oh) * p.OW * p.ldy + ch * E;
-                for (int ow = w0; ow <= w1; ++ow) {
-                    const float wt = wh * wt_of(ow, iw, p.sw, p.IW);
-                    if (wt == 0.f) continue;
-                    float g[E];
-                    Ch<T>::load(row + (long long)ow * p.ldy, g);
-#pragma unroll
-                    for (int e = 0; e < E; ++e) acc[e] = fmaf(wt, g[e], acc[e]);
-                }
-            }
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(wt, g[e], acc[e]);
         }
-        Ch<T>::store(dxg + v * p.ldx + ch * E, acc);
+        st4<TO>(gx + ((ou * p.Li + i) * p.inner + in) * p.lddx + ch * 4, acc);
     }
 }
 
@@ -241,35 +253,83 @@ __global__ __launch_bounds__(256) void kv_attn_kernel(const KvParams p) {
     }
 }
 
-// grid = (M, heads, B); thread = (channel c, query lane): dk[j][c] = sum_q dS[q][j] q[q][c], dv[j][c] = sum_q P[q][j] dO[q][c]
+// dk[j][c] = sum_q dS[q][j] q[q][c], dv[j][c] = sum_q P[q][j] dO[q][c].
+// Step 1, grid = (query chunks, heads, B): thread = (channel c, query lane) keeps the sums of up to KT keys in registers
+// over the queries of its chunk (P / dS rows of the chunk staged in LDS), lanes are added in a fixed order, the workgroup
+// leaves a partial [M][2][hd].  Step 2 adds the chunks in order.  Deterministic.
+constexpr int QCH = 128;     // queries per workgroup
+
 template <typename T>
-__global__ __launch_bounds__(256) void kv_attn_bwd_kv_kernel(const KvParams p) {
+__global__ __launch_bounds__(256) void kv_attn_bwd_kv_kernel(const KvParams p, float* part) {
+    __shared__ float sP[QCH][KT + 1];
+    __shared__ float sS[QCH][KT + 1];
     __shared__ float red[2][256];
-    const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int qc = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int HD = p.hd, C = p.heads * HD;
-    const int lanes = 256 / HD;                   // query lanes
+    const int lanes = 256 / HD;
     const int c = threadIdx.x % HD, ql = threadIdx.x / HD;
-    float ak = 0.f, av = 0.f;
-    if (ql < lanes) {
-        const T* qg = (const T*)p.q + (long long)b * p.N * C + h * HD + c;
-        const T* og = (const T*)p.dout + (long long)b * p.N * C + h * HD + c;
-        const float* Pg = p.P + ((long long)b * p.heads + h) * p.N * p.M + j;
-        const float* Sg = p.dS + ((long long)b * p.heads + h) * p.N * p.M + j;
-        for (int qi = ql; qi < p.N; qi += lanes) {
-            ak = fmaf(Sg[(long long)qi * p.M], ldf(qg + (long long)qi * C), ak);
-            av = fmaf(Pg[(long long)qi * p.M], ldf(og + (long long)qi * C), av);
+    const int q0 = qc * QCH, nq = min(QCH, p.N - q0);
+    const T* qg = (const T*)p.q + ((long long)b * p.N + q0) * C + h * HD + c;
+    const T* og = (const T*)p.dout + ((long long)b * p.N + q0) * C + h * HD + c;
+    const long long rbase = (((long long)b * p.heads + h) * p.N + q0) * p.M;
+    float* out = part + ((((long long)qc * gridDim.z + b) * p.heads + h) * p.M) * 2 * HD;
+    for (int j0 = 0; j0 < p.M; j0 += KT) {
+        const int nk = min(KT, p.M - j0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nq * nk; i += 256) {
+            const int qi = i / nk, j = i - qi * nk;
+            sP[qi][j] = p.P[rbase + (long long)qi * p.M + j0 + j];
+            sS[qi][j] = p.dS[rbase + (long long)qi * p.M + j0 + j];
+        }
+        __syncthreads();
+        float ak[KT], av[KT];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) ak[j] = av[j] = 0.f;
+        if (ql < lanes) {
+            for (int qi = ql; qi < nq; qi += lanes) {
+                const float qv = ldf(qg + (long long)qi * C), ov = ldf(og + (long long)qi * C);
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    if (j < nk) {
+                        ak[j] = fmaf(sS[qi][j], qv, ak[j]);
+                        av[j] = fmaf(sP[qi][j], ov, av[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            if (j < nk) {                    // nk is uniform over the workgroup
+                __syncthreads();
+                red[0][threadIdx.x] = ak[j];
+                red[1][threadIdx.x] = av[j];
+                __syncthreads();
+                if (threadIdx.x < HD) {
+                    float sk = 0.f, sv = 0.f;
+                    for (int l2 = 0; l2 < lanes; ++l2) { sk += red[0][l2 * HD + c]; sv += red[1][l2 * HD + c]; }
+                    out[((long long)(j0 + j) * 2 + 0) * HD + c] = sk;
+                    out[((long long)(j0 + j) * 2 + 1) * HD + c] = sv;
+                }
+            }
         }
     }
-    red[0][threadIdx.x] = ak;
-    red[1][threadIdx.x] = av;
-    __syncthreads();
-    if (threadIdx.x < HD) {
-        float sk = 0.f, sv = 0.f;
-        for (int l2 = 0; l2 < lanes; ++l2) { sk += red[0][l2 * HD + c]; sv += red[1][l2 * HD + c]; }
-        T* dg = (T*)p.dkv + ((long long)b * p.M + j) * 2 * C + h * HD + c;
-        dg[0] = (T)sk;
-        dg[C] = (T)sv;
+}
+
+// grid = (M, heads, B), HD threads: dkv[b][j][h*hd + c] (k half, v half) = sum over query chunks, in order
+template <typename T>
+__global__ void kv_attn_bwd_kv_finalize_kernel(const KvParams p, const float* part, int nqc) {
+    const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z, c = threadIdx.x;
+    const int HD = p.hd, C = p.heads * HD;
+    if (c >= HD) return;
+    float sk = 0.f, sv = 0.f;
+    for (int qc = 0; qc < nqc; ++qc) {
+        const float* src = part + (((((long long)qc * gridDim.z + b) * p.heads + h) * p.M + j) * 2) * HD;
+        sk += src[c];
+        sv += src[HD + c];
     }
+    T* dg = (T*)p.dkv + ((long long)b * p.M + j) * 2 * C + h * HD + c;
+    dg[0] = (T)sk;
+    dg[C] = (T)sv;
 }
 
 template <typename T>
@@ -307,6 +367,15 @@ int interp_check(const void* lo, long long ldlo, const void* hi, long long ldhi,
     return MSSEG_OK;
 }
 
+template <typename TI, typename TO>
+int interp1_launch(const void* dy, long long lddy, void* dx, long long lddx, long long outer, int Lo, int Li, long long inner,
+                          int C, hipStream_t stream) {
+    Interp1Params p{dy, lddy, dx, lddx, outer, inner, Lo, Li, C, (float)Li / Lo};
+    hipLaunchKernelGGL((interp1_bwd_kernel<TI, TO>), dim3(grid_of(outer * Li * inner * (C / 4))), dim3(256), 0, stream, p);
+    MSSEG_CHECK_LAUNCH("interp_trilinear_bwd");
+    return MSSEG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -323,16 +392,31 @@ int msseg_interp_trilinear_fwd(const void* x, long long ldx, void* y, long long 
     return MSSEG_OK;
 }
 
+size_t msseg_interp_trilinear_bwd_workspace_bytes(int N, int ID, int IH, int IW, int OD, int OH, int OW, int C) {
+    (void)ID;
+    return ((size_t)N * OD * OH * IW + (size_t)N * OD * IH * IW) * C * sizeof(float);
+}
+
 int msseg_interp_trilinear_bwd(const void* dy, long long lddy, void* dx, long long lddx, int N, int ID, int IH, int IW, int OD,
-                               int OH, int OW, int C, int dtype, msseg_stream_t stream) {
+                               int OH, int OW, int C, void* workspace, size_t workspace_bytes, int dtype, msseg_stream_t stream) {
     int rc = interp_check(dx, lddx, dy, lddy, N, ID, IH, IW, OD, OH, OW, C, dtype, "interp_trilinear_bwd");
     if (rc) return rc;
-    InterpParams p{dx, lddx, (void*)dy, lddy, N, ID, IH, IW, OD, OH, OW, C, (float)ID / OD, (float)IH / OH, (float)IW / OW};
-    const long long total = (long long)N * ID * IH * IW * (C / (dtype == MSSEG_F32 ? 4 : 8));
-    if (dtype == MSSEG_F32) hipLaunchKernelGGL(interp_bwd_kernel<float>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(interp_bwd_kernel<bf16_t>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, p);
-    MSSEG_CHECK_LAUNCH("interp_trilinear_bwd");
-    return MSSEG_OK;
+    const size_t need = msseg_interp_trilinear_bwd_workspace_bytes(N, ID, IH, IW, OD, OH, OW, C);
+    if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < need)
+        MSSEG_FAIL(MSSEG_EWORKSPACE, "interp_trilinear_bwd: needs a 16-byte aligned workspace of %zu bytes", need);
+    float* t1 = (float*)workspace;                               // [N, OD, OH, IW, C]
+    float* t2 = t1 + (size_t)N * OD * OH * IW * C;               // [N, OD, IH, IW, C]
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MSSEG_F32) {
+        rc = interp1_launch<float, float>(dy, lddy, t1, C, (long long)N * OD * OH, OW, IW, 1, C, st);
+        if (!rc) rc = interp1_launch<float, float>(t1, C, t2, C, (long long)N * OD, OH, IH, IW, C, st);
+        if (!rc) rc = interp1_launch<float, float>(t2, C, dx, lddx, N, OD, ID, (long long)IH * IW, C, st);
+    } else {
+        rc = interp1_launch<bf16_t, float>(dy, lddy, t1, C, (long long)N * OD * OH, OW, IW, 1, C, st);
+        if (!rc) rc = interp1_launch<float, float>(t1, C, t2, C, (long long)N * OD, OH, IH, IW, C, st);
+        if (!rc) rc = interp1_launch<float, bf16_t>(t2, C, dx, lddx, N, OD, ID, (long long)IH * IW, C, st);
+    }
+    return rc;
 }
 
 static int kv_check(const KvParams& p, int dtype, const char* what) {
@@ -375,8 +459,9 @@ int msseg_kv_attention_fwd(const void* q, const void* kv, void* o, float* lse, i
     return MSSEG_OK;
 }
 
-size_t msseg_kv_attention_bwd_workspace_bytes(int B, int N, int M, int heads) {
-    return (size_t)2 * B * heads * N * M * sizeof(float);
+size_t msseg_kv_attention_bwd_workspace_bytes(int B, int N, int M, int heads, int head_dim) {
+    const size_t nqc = (size_t)(N + QCH - 1) / QCH;
+    return ((size_t)2 * B * heads * N * M + nqc * B * heads * M * 2 * head_dim) * sizeof(float);
 }
 
 int msseg_kv_attention_bwd(const void* q, const void* kv, const void* o, const float* lse, const void* dout, void* dq, void* dkv,
@@ -388,16 +473,23 @@ int msseg_kv_attention_bwd(const void* q, const void* kv, const void* o, const f
     p.B = B; p.N = N; p.M = M; p.heads = heads; p.hd = head_dim; p.scale = scale;
     int rc = kv_check(p, dtype, "kv_attention_bwd");
     if (rc) return rc;
-    const size_t need = msseg_kv_attention_bwd_workspace_bytes(B, N, M, heads);
+    const size_t need = msseg_kv_attention_bwd_workspace_bytes(B, N, M, heads, head_dim);
     if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < need)
         MSSEG_FAIL(MSSEG_EWORKSPACE, "kv_attention_bwd: needs a workspace of %zu bytes", need);
     p.P = (float*)workspace;
     p.dS = p.P + (size_t)B * heads * N * M;
     KV_DISPATCH(true);
     MSSEG_CHECK_LAUNCH("kv_attention_bwd (queries)");
-    const dim3 g2(M, heads, B);
-    if (dtype == MSSEG_F32) hipLaunchKernelGGL(kv_attn_bwd_kv_kernel<float>, g2, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(kv_attn_bwd_kv_kernel<bf16_t>, g2, dim3(256), 0, (hipStream_t)stream, p);
+    const int nqc = (N + QCH - 1) / QCH;
+    float* part = p.dS + (size_t)B * heads * N * M;
+    const dim3 g2(nqc, heads, B), g3(M, heads, B);
+    if (dtype == MSSEG_F32) {
+        hipLaunchKernelGGL(kv_attn_bwd_kv_kernel<float>, g2, dim3(256), 0, (hipStream_t)stream, p, part);
+        hipLaunchKernelGGL(kv_attn_bwd_kv_finalize_kernel<float>, g3, dim3(64), 0, (hipStream_t)stream, p, (const float*)part, nqc);
+    } else {
+        hipLaunchKernelGGL(kv_attn_bwd_kv_kernel<bf16_t>, g2, dim3(256), 0, (hipStream_t)stream, p, part);
+        hipLaunchKernelGGL(kv_attn_bwd_kv_finalize_kernel<bf16_t>, g3, dim3(64), 0, (hipStream_t)stream, p, (const float*)part, nqc);
+    }
     MSSEG_CHECK_LAUNCH("kv_attention_bwd (keys)");
     return MSSEG_OK;
 }

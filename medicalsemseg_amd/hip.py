@@ -38,9 +38,10 @@ SIGNATURES = {
     "msseg_dwconv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_dwconv3d_k3_wgrad": ([_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_interp_trilinear_fwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
-    "msseg_interp_trilinear_bwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_interp_trilinear_bwd_workspace_bytes": ([_i, _i, _i, _i, _i, _i, _i, _i], _sz),
+    "msseg_interp_trilinear_bwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_kv_attention_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
-    "msseg_kv_attention_bwd_workspace_bytes": ([_i, _i, _i, _i], _sz),
+    "msseg_kv_attention_bwd_workspace_bytes": ([_i, _i, _i, _i, _i], _sz),
     "msseg_kv_attention_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _i, _vp], _i),
     "msseg_scale_channels": ([_vp, _vp, _vp, _i, _ll, _i, _i, _vp], _i),
     "msseg_reduce_scratch_bytes": ([], _sz),
@@ -610,8 +611,11 @@ def interp_trilinear(x, y):
 def interp_trilinear_bwd(dy, dx):
     _need_gpu(dy, dx)
     N, ID, IH, IW, C = dx.shape
-    _ck(lib().msseg_interp_trilinear_bwd(_p(dy), ld(dy), _p(dx), ld(dx), N, ID, IH, IW, dy.shape[1], dy.shape[2], dy.shape[3],
-                                         C, dt(dx), _stream()), "interp_trilinear_bwd")
+    OD, OH, OW = dy.shape[1:4]
+    nb = lib().msseg_interp_trilinear_bwd_workspace_bytes(N, ID, IH, IW, OD, OH, OW, C)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dx.device)
+    _ck(lib().msseg_interp_trilinear_bwd(_p(dy), ld(dy), _p(dx), ld(dx), N, ID, IH, IW, OD, OH, OW, C, _p(ws), nb, dt(dx),
+                                         _stream()), "interp_trilinear_bwd")
     return dx
 
 
@@ -632,7 +636,7 @@ def kv_attention_bwd(q, kv, o, lse, dout, heads, scale):
     B, N, C = q.shape
     M = kv.shape[1]
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-    nb = lib().msseg_kv_attention_bwd_workspace_bytes(B, N, M, heads)
+    nb = lib().msseg_kv_attention_bwd_workspace_bytes(B, N, M, heads, C // heads)
     ws = torch.empty(nb, dtype=torch.uint8, device=q.device)
     _ck(lib().msseg_kv_attention_bwd(_p(q), _p(kv), _p(o), _p(lse), _p(dout), _p(dq), _p(dkv), B, N, M, heads, C // heads,
                                      scale, _p(ws), nb, dt(q), _stream()), "kv_attention_bwd")

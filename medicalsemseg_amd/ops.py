@@ -213,11 +213,25 @@ class Conv3Fn(torch.autograd.Function):
         return dx, None, None, None
 
 
+def _patchify(x, k):
+    """[B, D, H, W, C] -> [B, D/k, H/k, W/k, C k^3] with the patch flattened in the weight's own (ci, kd, kh, kw) order"""
+    B, D, H, W, C = x.shape
+    return x.view(B, D // k, k, H // k, k, W // k, k, C).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(B, D // k, H // k, W // k, C * k ** 3)
+
+
+def _unpatchify(xs, k, C):
+    B, d, h, w, _ = xs.shape
+    return xs.view(B, d, h, w, C, k, k, k).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(B, d * k, h * k, w * k, C)
+
+
 class PatchConvFn(torch.autograd.Function):
-    """Conv3d through the im2col-style gather kernel: kernel k, stride s (default k), padding p.  Used for patch
-    embeddings (few input channels: PatchEmbed3D.proj k = s = 2, SegFormer's OverlapPatchEmbed k7 s4 p3) and for the
-    spatial-reduction conv of SegFormer's attention (k = s, many channels), whose input gradient is a flat GEMM on the
-    [Cout, Cin k^3] view of the weight followed by a depth-to-space permute."""
+    """Conv3d with kernel k, stride s (default k), padding p outside the k3 kernels' reach.
+
+    * few input channels (PatchEmbed3D.proj k = s = 2, SegFormer's OverlapPatchEmbed k7 s4 p3 on the raw volume): the
+      im2col-style gather kernel; no input gradient (the input is the data).
+    * k = s, p = 0, channel count a multiple of the 16-byte chunk (the spatial-reduction conv of SegFormer's attention,
+      segformer_backbone.py:76-78): non-overlapping patches are a layout change, so the conv is ONE flat GEMM on the
+      weight's own [Cout, Cin k^3] view after a space-to-depth copy -- forward, input gradient and weight gradient."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, k, s=None, p=0):
@@ -226,13 +240,22 @@ class PatchConvFn(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         T = x.dtype
         B, D, H, W, _ = x.shape
+        ctx.weight, ctx.bias = weight, bias
+        ctx.k, ctx.s, ctx.p = k, s, p
+        ctx.gemm = (s == k and p == 0 and cin % (16 // x.element_size()) == 0 and D % k == 0 and H % k == 0 and W % k == 0)
+        if ctx.gemm:
+            K = cin * k ** 3
+            xs = _patchify(x, k)
+            wp = _packed(weight, T, "pf", lambda: hip.pack_conv_k1(weight.detach().reshape(cout, K), T))
+            y = torch.empty(xs.shape[:-1] + (cout,), dtype=T, device=x.device)
+            hip.conv3d_k1(xs, wp, bias, y, K, cout)
+            ctx.save_for_backward(xs)
+            return y
         wp = _packed(weight, T, "g", lambda: hip.pack_conv_gather(weight.detach().contiguous(), T))
         od, oh, ow = ((v + 2 * p - k) // s + 1 for v in (D, H, W))
         y = torch.empty(B, od, oh, ow, cout, dtype=T, device=x.device)
         hip.conv3d_gather(x, wp, bias, y, cin, cout, k, s, p)
         ctx.save_for_backward(x)
-        ctx.weight, ctx.bias = weight, bias
-        ctx.k, ctx.s, ctx.p = k, s, p
         return y
 
     @staticmethod
@@ -242,24 +265,28 @@ class PatchConvFn(torch.autograd.Function):
         dy = _c(dy)
         cout, cin = weight.shape[0], weight.shape[1]
         k = ctx.k
-        if ctx.needs_input_grad[1]:
-            g, acc = _gbuf(weight)
-            hip.conv3d_gather_wgrad(x, dy, g, cin, cout, k, ctx.s, ctx.p, acc)
         if bias is not None and ctx.needs_input_grad[2]:
             g, acc = _gbuf(bias)
             hip.channel_sum(dy, g, acc)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            B, D, H, W, _ = x.shape
-            if ctx.s != k or ctx.p != 0 or D % k or H % k or W % k:
-                raise NotImplementedError("input gradient of a gather conv needs kernel == stride, no padding")
-            T = x.dtype
+        if ctx.gemm:
             K = cin * k ** 3
-            wpd = _packed(weight, T, "gd", lambda: hip.pack_conv_k1(weight.detach().reshape(cout, K), T, dgrad=True))
-            dxs = torch.empty(dy.shape[:-1] + (K,), dtype=T, device=x.device)          # [B, d, h, w, (ci, kd, kh, kw)]
-            hip.conv3d_k1(dy, wpd, None, dxs, cout, K)
-            dx = dxs.view(B, D // k, H // k, W // k, cin, k, k, k).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(B, D, H, W, cin)
-        return dx, None, None, None, None, None
+            T = x.dtype
+            if ctx.needs_input_grad[1]:
+                g, acc = _gbuf(weight)
+                hip.conv3d_k1_wgrad(x, dy, g.view(cout, K), K, cout, acc)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                wpd = _packed(weight, T, "pd", lambda: hip.pack_conv_k1(weight.detach().reshape(cout, K), T, dgrad=True))
+                dxs = torch.empty_like(x)
+                hip.conv3d_k1(dy, wpd, None, dxs, cout, K)
+                dx = _unpatchify(dxs, k, cin)
+            return dx, None, None, None, None, None
+        if ctx.needs_input_grad[1]:
+            g, acc = _gbuf(weight)
+            hip.conv3d_gather_wgrad(x, dy, g, cin, cout, k, ctx.s, ctx.p, acc)
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("input gradient of a gather conv (few channels / overlapping patches) is not on this path")
+        return None, None, None, None, None, None
 
 
 class DwConv3Fn(torch.autograd.Function):
