@@ -202,11 +202,11 @@ int msseg_deconv_k2s2_wgrad(const void* x, long long ldx, const void* dy, long l
 /* ---------------------------------------------------------------------------------------------
  * Depthwise Conv3d k3 s1 p1 (groups = channels) of the SwinDepth MLP (models/backbones/swindepth.py:36-41,56-65).
  * x, y channels-last [N, D, H, W, C] (C % (16 / sizeof(elem)) == 0); w_taps = the weight [C, 1, 3, 3, 3] transposed to
- * tap-major fp32 [27][C]; flip = 1 mirrors the taps (the input gradient: dx = dwconv(dy, flip)).
+ * tap-major [27][C] in the tensors' dtype; flip = 1 mirrors the taps (the input gradient: dx = dwconv(dy, flip)).
  * wgrad: dw (torch layout [C, 1, 3, 3, 3], fp32) and dbias [C] written or accumulated; partial rows in `scratch`
  * (msseg_reduce_scratch_bytes()), added in row order by a second kernel -- deterministic.
  * ------------------------------------------------------------------------------------------- */
-int msseg_dwconv3d_k3_fwd(const void* x, long long ldx, const float* w_taps, const float* bias, void* y, long long ldy, int N,
+int msseg_dwconv3d_k3_fwd(const void* x, long long ldx, const void* w_taps, const float* bias, void* y, long long ldy, int N,
                           int D, int H, int W, int C, int flip, int dtype, msseg_stream_t stream);
 int msseg_dwconv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, float* dbias,
                             int accumulate_w, int accumulate_b, int N, int D, int H, int W, int C, void* scratch,

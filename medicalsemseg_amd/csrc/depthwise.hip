@@ -43,7 +43,7 @@ template <> struct Chunk<float> {
 
 struct DwParams {
     const void* x; long long ldx;
-    const float* w;        // [27][C] tap-major fp32
+    const void* w;         // [27][C] tap-major, compute dtype (one 16-byte chunk per tap and thread)
     const float* bias;     // [C] or null
     void* y; long long ldy;
     int N, D, H, W, C;
@@ -67,25 +67,26 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(const DwParams p) {
         float acc[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = p.bias ? p.bias[c0 + e] : 0.f;
+        // branch-free: out-of-volume taps read the centre voxel and are multiplied by zero, so that all 27 + 27 loads of a
+        // thread can be in flight together
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) {
-            const int d = d0 + kd - 1;
-            if ((unsigned)d >= (unsigned)p.D) continue;
+            const bool okd = (unsigned)(d0 + kd - 1) < (unsigned)p.D;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                const int h = h0 + kh - 1;
-                if ((unsigned)h >= (unsigned)p.H) continue;
+                const bool okh = okd && (unsigned)(h0 + kh - 1) < (unsigned)p.H;
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const int w = w0 + kw - 1;
-                    if ((unsigned)w >= (unsigned)p.W) continue;
+                    const bool ok = okh && (unsigned)(w0 + kw - 1) < (unsigned)p.W;
                     const int tap = (kd * 3 + kh) * 3 + kw;
-                    const float* wt = p.w + (long long)(p.flip ? 26 - tap : tap) * p.C + c0;
-                    const long long nv = v + ((long long)(kd - 1) * p.H + (kh - 1)) * p.W + (kw - 1);
+                    float wt[E];
+                    Chunk<T>::load((const T*)p.w + (long long)(p.flip ? 26 - tap : tap) * p.C + c0, wt);
+                    const long long nv = ok ? v + ((long long)(kd - 1) * p.H + (kh - 1)) * p.W + (kw - 1) : v;
                     float xv[E];
                     Chunk<T>::load(xg + nv * p.ldx + c0, xv);
+                    const float m = ok ? 1.f : 0.f;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) acc[e] = fmaf(xv[e], wt[e], acc[e]);
+                    for (int e = 0; e < E; ++e) acc[e] = fmaf(xv[e] * m, wt[e], acc[e]);
                 }
             }
         }
@@ -125,31 +126,35 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const DwWgParams p) 
     long long v_end = v_begin + p.vox_per_row;
     if (v_end > NV) v_end = NV;
     if (live) {
-        for (long long v = v_begin + wave; v < v_end; v += 4) {
-            const int w0 = (int)(v % p.W); long long t = v / p.W;
-            const int h0 = (int)(t % p.H); t /= p.H;
-            const int d0 = (int)(t % p.D);
-            float g[E];
-            Chunk<T>::load(gg + v * p.lddy + c0, g);
-            if (kd == 1) {
+        // two voxels per iteration: twenty independent loads in flight per lane instead of ten (the loop is latency-bound)
+        for (long long vv = v_begin + wave; vv < v_end; vv += 8) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) bacc[e] += g[e];
-            }
-            const int d = d0 + kd - 1;
-            if ((unsigned)d >= (unsigned)p.D) continue;
+            for (int u = 0; u < 2; ++u) {
+                const long long v = vv + 4 * u;
+                if (v >= v_end) continue;
+                const int w0 = (int)(v % p.W); long long t = v / p.W;
+                const int h0 = (int)(t % p.H); t /= p.H;
+                const int d0 = (int)(t % p.D);
+                float g[E];
+                Chunk<T>::load(gg + v * p.lddy + c0, g);
+                if (kd == 1) {
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int h = h0 + kh - 1;
-                if ((unsigned)h >= (unsigned)p.H) continue;
+                    for (int e = 0; e < E; ++e) bacc[e] += g[e];
+                }
+                const bool okd = (unsigned)(d0 + kd - 1) < (unsigned)p.D;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int w = w0 + kw - 1;
-                    if ((unsigned)w >= (unsigned)p.W) continue;
-                    const long long nv = v + ((long long)(kd - 1) * p.H + (kh - 1)) * p.W + (kw - 1);
-                    float xv[E];
-                    Chunk<T>::load(xg + nv * p.ldx + c0, xv);
+                for (int kh = 0; kh < 3; ++kh) {
+                    const bool okh = okd && (unsigned)(h0 + kh - 1) < (unsigned)p.H;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) acc[kh * 3 + kw][e] = fmaf(g[e], xv[e], acc[kh * 3 + kw][e]);
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const bool ok = okh && (unsigned)(w0 + kw - 1) < (unsigned)p.W;
+                        const long long nv = ok ? v + ((long long)(kd - 1) * p.H + (kh - 1)) * p.W + (kw - 1) : v;
+                        float xv[E];
+                        Chunk<T>::load(xg + nv * p.ldx + c0, xv);
+                        const float m = ok ? 1.f : 0.f;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) acc[kh * 3 + kw][e] = fmaf(g[e] * m, xv[e], acc[kh * 3 + kw][e]);
+                    }
                 }
             }
         }
@@ -179,14 +184,24 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const DwWgParams p) 
     }
 }
 
-// dw[c][tap] (torch layout [C, 1, 3, 3, 3]) and db[c] (+)= sum over rows, in row order
+// dw[c][tap] (torch layout [C, 1, 3, 3, 3]) and db[c] (+)= sum over rows: 64 columns x 4 row slots per block (slot s adds
+// rows s, s + 4, ... in order), slots combined in a fixed order -- bit-reproducible
 __global__ __launch_bounds__(256) void dwconv3_wgrad_finalize_kernel(const float* ws, int rows, int C, float* dw, float* db,
                                                                      int acc_w, int acc_b) {
-    const int i = blockIdx.x * 256 + threadIdx.x;      // i = t * C + c
-    if (i >= 28 * C) return;
-    const int t = i / C, c = i - t * C;
+    __shared__ float part[4][64];
+    const int col = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;               // i = t * C + c
+    const int L = 28 * C;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += ws[(long long)r * 28 * C + i];
+    if (i < L) {
+#pragma unroll 8
+        for (int r = slot; r < rows; r += 4) s += ws[(long long)r * L + i];
+    }
+    part[slot][col] = s;
+    __syncthreads();
+    if (slot != 0 || i >= L) return;
+    s = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
+    const int t = i / C, c = i - t * C;
     if (t < 27) {
         if (dw) dw[(long long)c * 27 + t] = acc_w ? dw[(long long)c * 27 + t] + s : s;
     } else if (db) {
@@ -208,11 +223,11 @@ int check(const void* x, long long ldx, const void* y, long long ldy, int N, int
 
 extern "C" {
 
-int msseg_dwconv3d_k3_fwd(const void* x, long long ldx, const float* w_taps, const float* bias, void* y, long long ldy, int N,
+int msseg_dwconv3d_k3_fwd(const void* x, long long ldx, const void* w_taps, const float* bias, void* y, long long ldy, int N,
                           int D, int H, int W, int C, int flip, int dtype, msseg_stream_t stream) {
     int rc = check(x, ldx, y, ldy, N, D, H, W, C, dtype, "dwconv3d_k3_fwd");
     if (rc) return rc;
-    if (!w_taps) MSSEG_FAIL(MSSEG_EINVAL, "dwconv3d_k3_fwd: null weight table");
+    if (!w_taps || ((uintptr_t)w_taps & 15)) MSSEG_FAIL(MSSEG_EINVAL, "dwconv3d_k3_fwd: weight table must be 16-byte aligned");
     DwParams p{x, ldx, w_taps, bias, y, ldy, N, D, H, W, C, flip ? 1 : 0};
     const long long total = (long long)N * D * H * W * (C / (dtype == MSSEG_F32 ? 4 : 8));
     long long gx = (total + 255) / 256;
@@ -239,7 +254,7 @@ int msseg_dwconv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long l
     if (rows < 1) MSSEG_FAIL(MSSEG_EINVAL, "dwconv3d_k3_wgrad: %d channels exceed the reduce scratch", C);
     const int epc = dtype == MSSEG_F32 ? 4 : 8;
     const int gy = ceil_div(3 * (C / epc), 64);
-    long long want = (long long)msseg_num_cus() * 4 / gy;      // a few workgroups per CU in total
+    long long want = (long long)msseg_num_cus() * 8 / gy;      // several workgroups per CU in total: the voxel loop is latency-bound
     if (want < 1) want = 1;
     if (rows > want) rows = want;
     if (rows > (NV + 3) / 4) rows = (NV + 3) / 4;
@@ -250,7 +265,7 @@ int msseg_dwconv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long l
     else
         hipLaunchKernelGGL(dwconv3_wgrad_kernel<bf16_t>, dim3((unsigned)rows, gy), dim3(256), 0, (hipStream_t)stream, p);
     MSSEG_CHECK_LAUNCH("dwconv3d_k3_wgrad");
-    hipLaunchKernelGGL(dwconv3_wgrad_finalize_kernel, dim3(ceil_div(28 * C, 256)), dim3(256), 0, (hipStream_t)stream, ws,
+    hipLaunchKernelGGL(dwconv3_wgrad_finalize_kernel, dim3(ceil_div(28 * C, 64)), dim3(256), 0, (hipStream_t)stream, ws,
                        (int)rows, C, dw, dbias, accumulate_w, accumulate_b);
     MSSEG_CHECK_LAUNCH("dwconv3d_k3_wgrad_finalize");
     return MSSEG_OK;

@@ -582,7 +582,9 @@ def _nsc(x):
 
 
 def dwconv3d_k3(x, w_taps, bias, y, flip=False):
-    """depthwise conv k3 p1 on channels-last x; w_taps fp32 [27, C] (tap-major); flip: the input gradient"""
+    """depthwise conv k3 p1 on channels-last x; w_taps [27, C] (tap-major, dtype of x); flip: the input gradient"""
+    if w_taps.dtype != x.dtype:
+        raise ValueError("dwconv3d_k3: the weight table must have the activation dtype")
     _need_gpu(x, w_taps, y)
     N, D, H, W, C = x.shape
     _ck(lib().msseg_dwconv3d_k3_fwd(_p(x), ld(x), _p(w_taps), _p(bias), _p(y), ld(y), N, D, H, W, C, int(flip), dt(x),

@@ -297,7 +297,7 @@ class DwConv3Fn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         x = _c(x)
         C = x.shape[-1]
-        taps = weight.detach().reshape(C, 27).t().contiguous().float()      # tap-major fp32 [27, C]
+        taps = weight.detach().reshape(C, 27).t().to(x.dtype).contiguous()  # tap-major [27, C] in the compute dtype
         ctx.save_for_backward(x, taps)
         ctx.weight, ctx.bias = weight, bias
         return hip.dwconv3d_k3(x, taps, bias.detach().float() if bias is not None else None, torch.empty_like(x))
