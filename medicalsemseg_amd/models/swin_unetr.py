@@ -281,11 +281,39 @@ class SwinUNETRCustom(nn.Module):
         self._build_ops()
         return r
 
+    # ---- two-phase backward (data-parallel overlap), same protocol as models/unet.py ----
+    # With `defer_backward_tail(True)` the autograd backward stops after the conv decoder (80 % of the 77 M parameters of
+    # Swin-UNETR-48: a suffix of the flat gradient buffer) and `backward_tail()` continues into the Swin encoder; the
+    # caller starts the all-reduce of the finished gradients in between (parallel.GradSync), which is what DDP's
+    # bucketed overlap does for the reference (/root/reference/run_training.py:82-85).
+    def defer_backward_tail(self, on: bool = True):
+        self._defer_tail = bool(on)
+        self._pending_tail = None
+        return self
+
+    def tail_parameters(self):
+        """parameters whose gradients `backward_tail()` produces"""
+        return list(self.encoder.parameters())
+
+    def backward_tail(self):
+        pend, self._pending_tail = getattr(self, "_pending_tail", None), None
+        if pend is not None:
+            feats, grads = pend
+            keep = [(f, g) for f, g in zip(feats, grads) if g is not None and f.requires_grad]
+            if keep:
+                torch.autograd.backward([f for f, _ in keep], [g for _, g in keep])
+
     def forward(self, x_in):
         if not isinstance(x_in, (tuple, list)):
             x_in = (x_in, None, None)
         feats, x_cl = self.encoder(x_in)
         dec_params = [p for m in (self.unet_encoders, self.unet_decoders, self.out) for p in m.parameters()]
+        if getattr(self, "_defer_tail", False) and torch.is_grad_enabled():
+            # two-phase backward: the decoder sees detached copies of the feature maps, so the first backward stops there
+            # (autograd would otherwise run the encoder's nodes with zero-filled gradients); backward_tail() feeds the
+            # gradients the decoder produced into the encoder's graph
+            self._tail_feats = feats
+            feats = [f.detach().requires_grad_(f.requires_grad) for f in feats]
         return _DecoderFn.apply(self, x_cl, len(feats), *feats, *dec_params)
 
 
@@ -341,4 +369,9 @@ class _DecoderFn(torch.autograd.Function):
                 dfeats[k - 1] = d
         dfeats[L - 1] = E[L].bwd(saved["enc"][L], g, need_dx=ctx.feat_needs[L - 1])
         ctx.saved = None
+        tail_feats = getattr(net, "_tail_feats", None)
+        if tail_feats is not None and getattr(net, "_defer_tail", False):
+            # two-phase backward: the encoder's part of the graph runs in net.backward_tail()
+            net._pending_tail, net._tail_feats = (tail_feats, dfeats), None
+            dfeats = [None] * nf
         return (None, None, None, *dfeats) + (None,) * (ctx.n_in - 3 - nf)

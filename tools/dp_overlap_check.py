@@ -1,6 +1,6 @@
 """Run under torch.distributed.run with 2 ranks on ONE GPU over gloo (tests/test_gpu_engine.py).
 
-Data-parallel step of the UNet with the two-phase backward: the flat gradient suffix the backward head finished is
+Data-parallel step of the UNet and of Swin-UNETR with the two-phase backward: the flat gradient suffix the backward head finished is
 all-reduced asynchronously while the backward tail runs (parallel.GradSync.start / finish).  Three optimiser steps are
 run in four arrangements and must leave bit-identical parameters on every rank:
   eager   + overlapped    eager   + one all-reduce after the whole backward
@@ -22,13 +22,23 @@ from medicalsemseg_amd.models.unet import UNET_FEATURES, UNet  # noqa: E402
 from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay  # noqa: E402
 
 
-def run(overlap: bool, graphs: bool, rank: int, dev):
+def build(kind, dev):
+    if kind == "unet":
+        return UNet(1, 2, UNET_FEATURES["UNetSmall"], compute_dtype=torch.bfloat16).to(dev)
+    # Swin-UNETR (reference encoder + UNETR decoder): the backward stops after the conv decoder, the encoder is the tail
+    from medicalsemseg_amd.models.swin_unetr import SwinTransformerNNFormer, SwinUNETRCustom
+    enc = SwinTransformerNNFormer((32, 32, 32), (2, 2, 2), 1, 16, (2, 2), (1, 2), (4, 4), drop_path_rate=0.0,
+                                  compute_dtype=torch.bfloat16)
+    return SwinUNETRCustom(enc, 1, 2, (32, 32, 32), 16, (2, 2, 2), compute_dtype=torch.bfloat16).to(dev)
+
+
+def run(overlap: bool, graphs: bool, rank: int, dev, kind="unet"):
     if overlap:
         os.environ.pop("MSSEG_NO_GRAD_OVERLAP", None)
     else:
         os.environ["MSSEG_NO_GRAD_OVERLAP"] = "1"
     torch.manual_seed(0)
-    net = UNet(1, 2, UNET_FEATURES["UNetSmall"], compute_dtype=torch.bfloat16).to(dev)
+    net = build(kind, dev)
     opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=1e-3, betas=(0.9, 0.95), eps=1e-6)
     torch.distributed.broadcast(opt.flat_param, src=0)
     layers.bump_weights_epoch()
@@ -98,18 +108,19 @@ def main():
     assert parallel.world_size() == 2
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
-    res = {}
-    for overlap in (True, False):
-        for graphs in (False, True):
-            res[(overlap, graphs)] = run(overlap, graphs, rank, dev)
-    ref = res[(False, False)]
-    for k, v in res.items():
-        assert torch.equal(v, ref), f"rank {rank}: arrangement overlap={k[0]} graphs={k[1]} differs: " \
-                                    f"{float((v - ref).abs().max())}"
-    # both ranks hold the same parameters
-    other = ref.clone()
-    torch.distributed.broadcast(other, src=0)
-    assert torch.equal(other, ref)
+    for kind in ("unet", "swin"):
+        res = {}
+        for overlap in (True, False):
+            for graphs in (False, True):
+                res[(overlap, graphs)] = run(overlap, graphs, rank, dev, kind)
+        ref = res[(False, False)]
+        for k, v in res.items():
+            assert torch.equal(v, ref), f"rank {rank}: {kind} arrangement overlap={k[0]} graphs={k[1]} differs: " \
+                                        f"{float((v - ref).abs().max())}"
+        # both ranks hold the same parameters
+        other = ref.clone()
+        torch.distributed.broadcast(other, src=0)
+        assert torch.equal(other, ref)
     torch.distributed.barrier()
     if rank == 0:
         print("DP_OVERLAP_OK", flush=True)
