@@ -1,0 +1,10 @@
+#!/bin/bash
+# end-of-round evidence: kernel-trace stats (eager launches) + the plain bench line of every workload, whole-step traffic
+mkdir -p gpurun_out
+for w in unet swin_unetr swin_unetr_official segformer3d swin_depth; do
+  bash tools/prof.sh r2f_prof_$w --workload $w --steps 10 --warmup 3 --no-graph > /dev/null 2>&1; tail -1 gpurun_out/r2f_prof_$w/summary.txt | cut -c1-120
+  timeout -k 10 400 python bench.py --workload $w > gpurun_out/r2f_bench_$w.json 2> gpurun_out/r2f_bench_$w.err; cut -c1-160 gpurun_out/r2f_bench_$w.json
+done
+MSSEG_NO_SW_GRAPH= bash tools/prof.sh r2f_prof_sliding_window --workload sliding_window --steps 1 --warmup 1 > /dev/null 2>&1; tail -1 gpurun_out/r2f_prof_sliding_window/summary.txt | cut -c1-120
+timeout -k 10 500 python bench.py --workload sliding_window > gpurun_out/r2f_bench_sliding_window.json 2> gpurun_out/r2f_bench_sliding_window.err; cut -c1-160 gpurun_out/r2f_bench_sliding_window.json
+bash tools/pmc_step.sh r2f --steps 3 --warmup 1 | head -3 | cut -c1-200
