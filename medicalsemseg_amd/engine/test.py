@@ -1,9 +1,9 @@
 """Evaluation / test-time inference: mirrors ``/root/reference/engine/test.py`` (``eval_model`` :15-94,
 ``test_model`` :96-173).  The label map is formed on the device (``msseg_argmax_u8``: the arg max of the blended logits,
 the reference's softmax is monotonic) and resampled to the original grid with ``msseg_resample_nearest_u8`` (the
-reference's ``resample_3d`` = scipy order-0 zoom, ``utils/misc.py:420-425``); only uint8 maps cross PCIe.  Hausdorff95
-and NIfTI writing are outside the hot path (nibabel is not available): maps are saved as ``.npy`` under the reference's
-directory layout."""
+reference's ``resample_3d`` = scipy order-0 zoom, ``utils/misc.py:420-425``); only uint8 maps cross PCIe.  Outputs go
+to the reference's directory layout as NIfTI-1 files (``utils/nifti.py``: nibabel is not available) when the input names
+carry a NIfTI extension, as ``.npy`` otherwise (synthetic loaders).  Hausdorff95 is outside the hot path."""
 from __future__ import annotations
 
 import os
@@ -76,12 +76,35 @@ def test_model(model, data_loader, device, cfg, log_writer=None):
                 seg_rs = hip.resample_nearest_u8(seg, target)
         if getattr(cfg, "save_eval_output", False) and cfg.output_dir:
             out_dir = os.path.join(cfg.output_dir, "test_output", "Fold" + str(getattr(cfg, "cv_fold", 0)))
-            os.makedirs(os.path.join(out_dir, "pred"), exist_ok=True)
-            np.save(os.path.join(out_dir, "pred", img_name + ".npy"), seg.cpu().numpy())
+            meta = batch["image_meta_dict"]
+            aff = _affine0(meta.get("affine"))                       # translation zeroed, as engine/test.py:151-152 does
+            _save_volume(os.path.join(out_dir, "pred"), img_name, seg.cpu().numpy(), aff)
+            if img_name.endswith((".nii", ".nii.gz")):
+                _save_volume(os.path.join(out_dir, "img"), img_name, inputs.squeeze().float().cpu().numpy(), aff)
             if seg_rs is not None:
-                os.makedirs(os.path.join(out_dir, "rs"), exist_ok=True)
-                np.save(os.path.join(out_dir, "rs", img_name + ".npy"), seg_rs.cpu().numpy())
+                _save_volume(os.path.join(out_dir, "rs"), img_name, seg_rs.cpu().numpy(), _affine0(meta.get("original_affine")))
     return None
+
+
+def _affine0(a):
+    """first affine of the batch with its translation set to zero (/root/reference/engine/test.py:151-152); identity when
+    the loader carries none"""
+    if a is None:
+        return np.eye(4)
+    a = np.array(torch.as_tensor(a).detach().cpu().numpy(), dtype=np.float64).reshape(-1, 4, 4)[0]
+    a[0:3, 3] = 0
+    return a
+
+
+def _save_volume(folder, name, arr, affine):
+    """NIfTI-1 (what nib.save(nib.Nifti1Image(arr, affine), path) writes, /root/reference/engine/test.py:160-170) for
+    names that carry a NIfTI extension, .npy otherwise (synthetic loaders)"""
+    os.makedirs(folder, exist_ok=True)
+    if name.endswith((".nii", ".nii.gz")):
+        from ..utils.nifti import save_nifti
+        save_nifti(os.path.join(folder, name), arr, affine)
+    else:
+        np.save(os.path.join(folder, name + ".npy"), arr)
 
 
 def majority_vote(fold_maps, n_classes: int) -> torch.Tensor:

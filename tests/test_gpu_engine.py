@@ -257,6 +257,24 @@ def test_eval_model_and_test_model_vs_oracle(tmp_path):
         rs = np.load(os.path.join(out_dir, "rs", f"synthetic_{i}_0.npy"))
         assert (pred != m).mean() < 1e-4
         assert rs.shape == (60, 41, 70) and np.array_equal(rs, resample_nearest(pred, (60, 41, 70)))
+    # file names with a NIfTI extension (the real datasets: "img0001.nii.gz"): NIfTI-1 outputs in pred/, img/ and rs/
+    class AsNifti:
+        def __iter__(self):
+            for i, b in enumerate(WithSpacing()):
+                b["image_meta_dict"]["filename_or_obj"] = [f"/data/img{i:04d}.nii.gz"]
+                b["image_meta_dict"]["affine"] = torch.diag(torch.tensor([-1.5, 1.5, 2.0, 1.0]))[None] + torch.tensor(
+                    [[[0, 0, 0, 7.0], [0, 0, 0, -3.0], [0, 0, 0, 11.0], [0, 0, 0, 0]]])
+                yield b
+    from medicalsemseg_amd.utils.nifti import load_nifti
+    test_model(net, AsNifti(), torch.device(DEV), cfg)
+    for i, m in enumerate(maps):
+        pred, aff = load_nifti(os.path.join(out_dir, "pred", f"{i:04d}.nii.gz"))
+        assert pred.dtype == np.uint8 and (pred != m).mean() < 1e-4
+        assert np.allclose(aff, np.diag([-1.5, 1.5, 2.0, 1.0]))            # translation zeroed as the reference does
+        img, _ = load_nifti(os.path.join(out_dir, "img", f"{i:04d}.nii.gz"))
+        assert img.shape == (48, 32, 64) and img.dtype == np.float32
+        rs, _ = load_nifti(os.path.join(out_dir, "rs", f"{i:04d}.nii.gz"))
+        assert rs.shape == (60, 41, 70)
     voted = majority_vote([maps[0], maps[0], maps[1]], 3).cpu().numpy()
     from oracle.postproc import majority_vote as mv_ref
     assert np.array_equal(voted, mv_ref(np.stack([maps[0], maps[0], maps[1]]), 3))

@@ -275,3 +275,32 @@ def test_segformer3d_and_swindepth_state_dict_keys_and_builder():
     net = build_model(cfg)
     enc = OW.SwinTransformerNNFormer((24, 24, 24), (2, 2, 2), 1, 32, (2, 2), (2, 4), (6, 3), mlp="depth")
     assert sorted(net.encoder.state_dict()) == sorted(enc.state_dict())
+
+
+def test_nifti_writer_round_trip_and_header(tmp_path):
+    """NIfTI-1 single-file writer (what nib.save(nib.Nifti1Image(arr, affine)) produces for the reference's test outputs):
+    header fields at their specified offsets, Fortran-ordered data, sform = affine, quaternion of a flipped-x affine"""
+    import struct
+    from medicalsemseg_amd.utils.nifti import load_nifti, save_nifti
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 5, size=(5, 6, 7)).astype(np.uint8)
+    aff = np.array([[-1.5, 0, 0, 10.0], [0, 1.5, 0, -20.0], [0, 0, 2.0, 5.0], [0, 0, 0, 1.0]])
+    for name in ("seg.nii", "seg.nii.gz"):
+        p = str(tmp_path / name)
+        save_nifti(p, arr, aff)
+        back, a2 = load_nifti(p)
+        assert back.dtype == np.uint8 and np.array_equal(back, arr) and np.allclose(a2, aff)
+    raw = open(tmp_path / "seg.nii", "rb").read()
+    assert len(raw) == 352 + arr.size
+    assert struct.unpack("<i", raw[0:4])[0] == 348 and raw[344:348] == b"n+1" + bytes(1)
+    assert struct.unpack("<8h", raw[40:56]) == (3, 5, 6, 7, 1, 1, 1, 1)
+    assert struct.unpack("<2h", raw[70:74]) == (2, 8)                               # DT_UINT8, 8 bits
+    assert np.allclose(struct.unpack("<4f", raw[76:92]), (-1.0, 1.5, 1.5, 2.0))      # qfac, voxel sizes
+    assert struct.unpack("<f", raw[108:112])[0] == 352.0
+    assert struct.unpack("<2h", raw[252:256]) == (0, 2)                              # qform unknown, sform aligned
+    assert np.allclose(struct.unpack("<3f", raw[256:268]), (0.0, 1.0, 0.0))          # 180 degrees about y after the z flip
+    assert raw[352:352 + 5] == arr[:, 0, 0].tobytes()                                # first index fastest
+    vol = rng.standard_normal((3, 4, 2)).astype(np.float32)
+    save_nifti(str(tmp_path / "img.nii.gz"), vol, np.eye(4))
+    back, _ = load_nifti(str(tmp_path / "img.nii.gz"))
+    assert back.dtype == np.float32 and np.array_equal(back, vol)
