@@ -49,6 +49,17 @@ MSSEG_DEVFN void glds16(const void* g, void* l) {
 
 struct TileCo { int n, d0, h0, w0; };
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+MSSEG_DEVFN unsigned pack_bf16x2(float a, float b) {            // one v_cvt_pk_bf16_f32 (round to nearest even)
+    const bf16x2_t v = {(bf16_t)a, (bf16_t)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+MSSEG_DEVFN float bf16_of_pair(unsigned u, int hi) {            // element `hi` of a packed pair as f32: one shift / mask
+    return __builtin_bit_cast(float, hi ? (u & 0xffff0000u) : (u << 16));
+}
+MSSEG_DEVFN void acc_add(float& s, float v) { asm("v_add_f32 %0, %0, %1" : "+v"(s) : "v"(v)); }
+MSSEG_DEVFN void acc_fma(float& s, float a, float b) { asm("v_fmac_f32 %0, %1, %2" : "+v"(s) : "v"(a), "v"(b)); }
+
 template <int STATS, int TIMING>
 __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -139,13 +150,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
 
     unsigned long long tcyc[6] = {0, 0, 0, 0, 0, 0};
     f32x4_t acc[TH][2];
+    // the bias is the accumulators' initial value: the epilogue (memory role, which shares its SIMD's vector issue
+    // with the other group's MFMAs) has no add left to do
+    f32x4_t bv[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4_t*)(p.bias + coutblk * 32 + j * 16 + q * 4);
+    }
 
     // ---- the MFMA role ------------------------------------------------------------------------------
     auto compute = [&]() {
 #pragma unroll
         for (int m = 0; m < TH; ++m)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j) acc[m][j] = bv[j];
         const unsigned char* xb = ldsH + grp * HALO_BYTES + q * PLANE + ((wq * PH) * PW + r) * 16;
         const unsigned char* wb = ldsW + (q * 32 + r) * 16;
         constexpr int NSTEP = 9 * PH;       // (kd, kw) x halo row
@@ -197,11 +215,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
         ny_off[m] = (unsigned)(rel * p.nb_ldy * 2 + q * 8);
         na_off[m] = (unsigned)(rel * p.nb_lda * 2 + q * 8);
     }
-    f32x4_t bv[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-    if (p.bias) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bv[j] = *(const f32x4_t*)(p.bias + coutblk * 32 + j * 16 + q * 4);
-    }
     // running (sum, sum2) of sample s_n: per lane across tiles, reduced over the 16 voxel lanes (fixed butterfly
     // order) into this wave's private LDS slot when the sample changes and at the end: deterministic, no atomics
     float s1[2][4], s2[2][4];
@@ -243,46 +256,59 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
         auto body = [&](auto fullc) {
             constexpr bool FULL = decltype(fullc)::value;
             const bool okdw = FULL || (tc.d0 + wq < p.D && tc.w0 + r < p.W);
-            bf16x4_t y4[TH][2], a4[TH][2];
+            u32x2_t y4[TH][2], a4[TH][2];
             if constexpr (STATS == 2) {
 #pragma unroll
                 for (int m = 0; m < TH; ++m)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const bool ok = FULL || (okdw && tc.h0 + m < p.H);
-                        y4[m][j] = a4[m][j] = bf16x4_t{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                        y4[m][j] = a4[m][j] = u32x2_t{0u, 0u};
                         if (ok) {
-                            y4[m][j] = *(const bf16x4_t*)(nyb + ny_off[m] + j * 32);
-                            a4[m][j] = *(const bf16x4_t*)(nab + na_off[m] + j * 32);
+                            y4[m][j] = *(const u32x2_t*)(nyb + ny_off[m] + j * 32);
+                            a4[m][j] = *(const u32x2_t*)(nab + na_off[m] + j * 32);
                         }
                     }
             }
+            // Everything below is vector-ALU work of a wave whose SIMD is issuing the other group's MFMAs: a 16x16x32
+            // MFMA leaves two 4-cycle issue slots per gap, and packed-f32 instructions cost several slots each
+            // (MI355X_MICROARCH.md, cycle constants).  So: ONE v_cvt_pk_bf16_f32 per output pair, the rounded values
+            // recovered from the packed word by a shift / a mask, and plain v_add_f32 / v_fmac_f32 accumulation (inline
+            // asm: the compiler would pair them into v_pk_add_f32).
+            // all stores first (they are what the phase's closing s_waitcnt vmcnt(0) waits for), the sums afterwards
+            u32x2_t ob[TH][2];
 #pragma unroll
             for (int m = 0; m < TH; ++m)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const bool ok = FULL || (okdw && tc.h0 + m < p.H);
-                    const f32x4_t o = acc[m][j] + bv[j];
-                    const bf16x4_t ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
-                    if (ok) *(bf16x4_t*)(ybase + o_off[m] + j * 32) = ob;
-                    if constexpr (STATS == 1) {
+                    const f32x4_t o = acc[m][j];
+                    ob[m][j] = u32x2_t{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    if (ok) *(u32x2_t*)(ybase + o_off[m] + j * 32) = ob[m][j];
+                }
+            if constexpr (STATS != 0) {
+#pragma unroll
+                for (int m = 0; m < TH; ++m)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bool ok = FULL || (okdw && tc.h0 + m < p.H);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float rv = ok ? (float)ob[e] : 0.f;   // statistics of the tensor as stored
-                            s1[j][e] += rv;
-                            s2[j][e] += rv * rv;
-                        }
-                    } else if constexpr (STATS == 2) {
-                        // dz = da * lrelu'(a); accumulate (sum dz, sum dz * yraw); xhat is formed by the finalising block
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float da = ok ? (float)ob[e] : 0.f;
-                            const float dz = (float)a4[m][j][e] > 0.f ? da : da * p.nb_slope;
-                            s1[j][e] += dz;
-                            s2[j][e] += dz * (float)y4[m][j][e];
+                            float v = bf16_of_pair(ob[m][j][e >> 1], e & 1);   // the value as stored
+                            if (!FULL) v = ok ? v : 0.f;
+                            if constexpr (STATS == 1) {
+                                acc_add(s1[j][e], v);
+                                acc_fma(s2[j][e], v, v);
+                            } else {
+                                // dz = da * lrelu'(a); accumulate (sum dz, sum dz * yraw); xhat is formed by the finalising block
+                                const float av = bf16_of_pair(a4[m][j][e >> 1], e & 1);
+                                const float dz = v * (av > 0.f ? 1.0f : p.nb_slope);
+                                acc_add(s1[j][e], dz);
+                                acc_fma(s2[j][e], dz, bf16_of_pair(y4[m][j][e >> 1], e & 1));
+                            }
                         }
                     }
-                }
+            }
         };
         if (full) body(std::true_type{});
         else body(std::false_type{});
@@ -375,7 +401,7 @@ bool msseg_k3pp_eligible(const K3ppParams& p) {
 int msseg_k3pp_launch(const K3ppParams& p, hipStream_t stream) {
     static const bool timing = getenv("MSSEG_K3PP_TIMING") != nullptr;
     if (p.stats == nullptr) return timing ? launch<0, 1>(p, stream) : launch<0, 0>(p, stream);
-    if (p.nb_y == nullptr) return launch<1, 0>(p, stream);
+    if (p.nb_y == nullptr) return timing ? launch<1, 1>(p, stream) : launch<1, 0>(p, stream);
     return launch<2, 0>(p, stream);
 }
 
