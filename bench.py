@@ -55,6 +55,11 @@ WORK = {
                    "metric": "96^3 vols/sec fwd+bwd (train), SwinDepth-48",
                    "name": "SwinDepth 48-feat (reference encoder swindepth: depthwise-conv + BatchNorm MLP, depths 2-2-2-2, heads "
                            "3-6-12-24, windows 6-6-6-3, patch 2 + UNETR decoder) 1->{c}cls, {s}^3 patches, DiceCE + AdamW, per-GPU batch {b}"},
+    "swinception": {"gflop_per_vol": None, "gb_per_vol_bf16": None,
+                    "metric": "96^3 vols/sec fwd+bwd (train), SwInception-48",
+                    "name": "SwInception 48-feat (reference encoder swinception: Inception-head MLP of Conv3d + BatchNorm3d + GELU "
+                            "branches, depths 2-2-2-2, heads 3-6-12-24, windows 6-6-6-3, patch 2 + UNETR decoder) 1->{c}cls, {s}^3 "
+                            "patches, DiceCE + AdamW, per-GPU batch {b}"},
     "sliding_window": {"gflop_per_vol": 252.4e3, "gb_per_vol_bf16": 714.0,
                        "metric": "512^3 sliding-window vols/sec",
                        "name": "UNet base 1->{c}cls, {v}^3 volume, roi {s}^3, overlap 0.5, gaussian, {w} windows, sw_batch {b}"},
@@ -114,6 +119,10 @@ def cpu_baseline_train(workload, batch, size, n_cls, budget_s=25.0):
         from oracle import swin as O
         net = O.SwinUNETRCustom(O.SwinTransformerNNFormer((size,) * 3, mlp="depth"), 1, n_cls, 48, 2)
         what = "oracle/ SwinUNETRCustom(SwinDepth 48)"
+    elif workload == "swinception":
+        from oracle import swin as O
+        net = O.SwinUNETRCustom(O.SwinTransformerNNFormer((size,) * 3, mlp="inception"), 1, n_cls, 48, 2)
+        what = "oracle/ SwinUNETRCustom(SwInception 48)"
     else:
         from oracle import swin as O
         net = O.SwinUNETRCustom(O.SwinTransformerNNFormer((size,) * 3), 1, n_cls, 48, 2)
@@ -294,9 +303,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
     ap.add_argument("--split-graph", action="store_true",
                     help="single GPU: use the multi-GPU replay structure (graph A | eager gap | graph B)")
-    ap.add_argument("--workload", default="unet", choices=["unet", "swin_unetr", "swin_unetr_official", "sliding_window", "segformer3d", "swin_depth"],
+    ap.add_argument("--workload", default="unet", choices=["unet", "swin_unetr", "swin_unetr_official", "sliding_window", "segformer3d", "swin_depth",
+                                                         "swinception"],
                     help="unet = the headline (BASELINE configs[1]); swin_unetr = configs[3]; sliding_window = configs[4]; "
-                         "segformer3d / swin_depth = the SURVEY 8(f) N3 / N4 model families")
+                         "segformer3d / swin_depth / swinception = the SURVEY 8(f) N3 / N4 model families")
     ap.add_argument("--sw-size", type=int, default=512)
     ap.add_argument("--sw-batch", type=int, default=8)   # windows per forward
     args = ap.parse_args()
@@ -331,9 +341,10 @@ def main():
                                       drop_path_rate=0.0, compute_dtype=dtype)
         net = SwinUNETRCustom(enc, 1, args.classes, (args.size,) * 3, 48, (2, 2, 2), compute_dtype=dtype).to(dev)
         args.no_graph = args.no_graph or bool(os.environ.get("MSSEG_SWIN_NO_GRAPH"))
-    elif args.workload == "swin_depth":
-        from medicalsemseg_amd.models.swin_unetr import SwinDepth, SwinUNETRCustom
-        enc = SwinDepth((args.size,) * 3, (2, 2, 2), 1, 48, (2, 2, 2, 2), (3, 6, 12, 24), (6, 6, 6, 3), drop_path_rate=0.0,
+    elif args.workload in ("swin_depth", "swinception"):
+        from medicalsemseg_amd.models.swin_unetr import SwInception, SwinDepth, SwinUNETRCustom
+        enc_cls = SwinDepth if args.workload == "swin_depth" else SwInception
+        enc = enc_cls((args.size,) * 3, (2, 2, 2), 1, 48, (2, 2, 2, 2), (3, 6, 12, 24), (6, 6, 6, 3), drop_path_rate=0.0,
                         compute_dtype=dtype)
         net = SwinUNETRCustom(enc, 1, args.classes, (args.size,) * 3, 48, (2, 2, 2), compute_dtype=dtype).to(dev)
         if world > 1:

@@ -7,6 +7,8 @@ for the models on the hot path.
   at ``model_builder.py:15-66``.
 * ``cfg.model == 'SwinDepth'`` -- the same wiring around the ``SwinDepth`` encoder (depthwise-conv + BatchNorm MLP), the
   branch at ``model_builder.py:120-171``.
+* ``cfg.model == 'SwInception'`` -- the same wiring around the ``SwInception`` encoder (Inception-head MLP: Conv3d +
+  BatchNorm3d + GELU branches with 6- / 38-channel convolutions at width 48), the branch at ``model_builder.py:67-119``.
 * ``cfg.model == 'SegFormer3D'`` -- ``MixVisionTransformer`` + ``SegFormerHeadOfficial`` (``model_builder.py:190-205``).
 * ``cfg.model == 'SwinUNETR'`` -- the vendored MONAI variant of ``models/segmentors/swin_unetr_official.py`` (window 7,
   ``feature_size = cfg.hidden_dim``), the literal "Swin-UNETR 48-feat" of BASELINE.json configs[3] (the reference keeps
@@ -20,7 +22,7 @@ import torch
 
 from .unet import UNET_FEATURES, UNet
 
-OUT_OF_SCOPE = ("SwInception", "SwinSegFormer", "GCViTUNETR", "FocalNetUNETR")
+OUT_OF_SCOPE = ("SwinSegFormer", "GCViTUNETR", "FocalNetUNETR")
 
 
 def _dtype(cfg):
@@ -40,13 +42,13 @@ def build_model(cfg):
     name = cfg.model
     if name in UNET_FEATURES:
         return UNet(cfg.in_chans, cfg.output_dim, UNET_FEATURES[name], compute_dtype=_dtype(cfg))
-    if name in ("nnFormerUNETR", "SwinDepth"):
-        from .swin_unetr import SwinDepth, SwinTransformerNNFormer, SwinUNETRCustom
+    if name in ("nnFormerUNETR", "SwinDepth", "SwInception"):
+        from .swin_unetr import SwInception, SwinDepth, SwinTransformerNNFormer, SwinUNETRCustom
         for flag in ("learned_cls_vectors", "rel_pos_bias_affine", "rel_crop_pos_emb", "abs_pos_emb", "global_token"):
             if getattr(cfg, flag, False):
                 raise NotImplementedError(f"--{flag} is outside the hot-path scope of this build (SURVEY.md section 2)")
         ws = cfg.window_size if isinstance(cfg.window_size, (tuple, list)) else (cfg.window_size,) * len(cfg.depths)
-        enc_cls = SwinDepth if name == "SwinDepth" else SwinTransformerNNFormer      # model_builder.py:120-171
+        enc_cls = {"SwinDepth": SwinDepth, "SwInception": SwInception}.get(name, SwinTransformerNNFormer)   # model_builder.py:67-171
         encoder = enc_cls(pretrain_img_size=_t3(cfg.vol_size), patch_size=_t3(cfg.patch_size), in_chans=cfg.in_chans,
                           embed_dim=cfg.hidden_dim, depths=tuple(cfg.depths), num_heads=tuple(cfg.num_heads),
                           window_size=tuple(ws), qkv_bias=cfg.qkv_bias, mlp_ratio=getattr(cfg, "mlp_ratio", 4.0),
@@ -67,5 +69,5 @@ def build_model(cfg):
                          num_heads=tuple(cfg.num_heads), feature_size=cfg.hidden_dim, compute_dtype=_dtype(cfg))
     if name in OUT_OF_SCOPE:
         raise NotImplementedError(f"model '{name}' is a research variant outside this build's hot-path scope "
-                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR', 'SwinDepth', 'SegFormer3D', 'SwinUNETR']")
+                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR', 'SwinDepth', 'SwInception', 'SegFormer3D', 'SwinUNETR']")
     raise ValueError(f"unknown cfg.model '{name}'")

@@ -63,6 +63,152 @@ class _DepthMlp(nn.Module):
         return ops.linear(y, self.fc2.weight, self.fc2.bias)
 
 
+def _p8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+class _PaddedState:
+    """Mixin for modules whose compute-side parameters are ZERO-PADDED versions of the reference's (channel counts raised
+    to multiples of 8 = one 16-byte bf16 chunk, so every kernel keeps its vector paths).  `_real` maps a local parameter /
+    buffer name to the reference shape; the state dict shows (and accepts) the reference shapes.
+
+    The padding entries stay exactly zero through training: a padded output channel has zero weights and bias, a zero
+    BatchNorm scale and shift, so its activation is 0 and every gradient that reaches a padding entry is a sum of
+    products with those zeros; AdamW maps (p, m, v) = (0, 0, 0) to 0."""
+
+    def _init_padded(self):
+        self._register_state_dict_hook(_PaddedState._slice_hook)
+        self._register_load_state_dict_pre_hook(self._pad_hook)
+        self.zero_padding_()
+
+    def _cut(self, name, t):
+        return t[tuple(slice(0, n) for n in self._real[name])]
+
+    @torch.no_grad()
+    def zero_padding_(self):
+        own = dict(self.named_parameters())
+        own.update(dict(self.named_buffers()))
+        for name in self._real:
+            t = own[name]
+            keep = self._cut(name, t).clone()
+            t.zero_()
+            self._cut(name, t).copy_(keep)
+
+    @staticmethod
+    def _slice_hook(module, state, prefix, local_metadata):
+        for name in module._real:
+            state[prefix + name] = module._cut(name, state[prefix + name]).clone()
+
+    def _pad_hook(self, state, prefix, local_metadata, strict, missing, unexpected, errors):
+        own = dict(self.named_parameters())
+        own.update(dict(self.named_buffers()))
+        for name, real in self._real.items():
+            v = state.get(prefix + name)
+            if v is not None and tuple(v.shape) == tuple(real) and tuple(v.shape) != tuple(own[name].shape):
+                full = torch.zeros(own[name].shape, dtype=v.dtype, device=v.device)
+                self._cut(name, full).copy_(v)
+                state[prefix + name] = full
+
+
+class _BasicConv3d(nn.Module, _PaddedState):
+    """Conv3d(bias) -> BatchNorm3d(eps 1e-3) -> GELU of the Inception head (/root/reference/models/backbones/swinception.py:45-56),
+    channel counts padded to multiples of 8 (see _PaddedState)"""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.k = k
+        self.conv = nn.Conv3d(_p8(cin), _p8(cout), kernel_size=k, padding=k // 2, bias=True)
+        self.bn = nn.BatchNorm3d(_p8(cout), eps=0.001)
+        # the reference's layer draws its default initialisation from the REAL fan-in
+        ref = nn.Conv3d(cin, cout, kernel_size=k, padding=k // 2, bias=True)
+        with torch.no_grad():
+            self.conv.weight.zero_(); self.conv.bias.zero_()
+            self.conv.weight[:cout, :cin].copy_(ref.weight); self.conv.bias[:cout].copy_(ref.bias)
+        self._real = {"conv.weight": (cout, cin, k, k, k), "conv.bias": (cout,), "bn.weight": (cout,), "bn.bias": (cout,),
+                      "bn.running_mean": (cout,), "bn.running_var": (cout,)}
+        self._init_padded()
+
+    def run(self, x, group):
+        c = self.conv
+        y = ops.linear(x, c.weight, c.bias) if self.k == 1 else ops.Conv3Fn.apply(x, c.weight, c.bias, 1)
+        return ops.gelu(ops.batch_norm(y, self.bn, group))
+
+
+class _InceptionBranch(nn.Module):
+    NAMES = (("branch1x1",), ("branch3x3_1", "branch3x3_2"), ("branch3x3dbl_1", "branch3x3dbl_2", "branch3x3dbl_3"),
+             ("branch3x3trpl_1", "branch3x3trpl_2", "branch3x3trpl_3", "branch3x3trpl_4"), ("branch_pool_2",))
+
+    def __init__(self, kind, cin, cout, bottleneck_divisor=8):
+        super().__init__()
+        self.kind = kind
+        names = self.NAMES[kind]
+        bn_dim = cin // bottleneck_divisor
+        dims = [cin] + [bn_dim] * (len(names) - 1) + [cout]
+        for i, n in enumerate(names):
+            self.add_module(n, _BasicConv3d(dims[i], dims[i + 1], 1 if (i == 0 or len(names) == 1) else 3))
+
+    def run(self, x, group):
+        if self.kind == 4:
+            x = ops.avg_pool3(x)
+        for n in self.NAMES[self.kind]:
+            x = getattr(self, n).run(x, group)
+        return x
+
+
+class _InceptionFc(nn.Linear, _PaddedState):
+    """Linear over the concatenated branches; the compute-side weight has one zero-padded slot of p8(branch) columns per
+    branch: reference [dim, 5 * branch] <-> padded [dim, 5 * p8(branch)]"""
+
+    def __init__(self, branch, nb, dim):
+        nn.Linear.__init__(self, nb * _p8(branch), dim)
+        self.branch, self.nb = branch, nb
+        ref = nn.Linear(nb * branch, dim)
+        with torch.no_grad():
+            self.weight.zero_()
+            self._slots(self.weight).copy_(ref.weight.view(dim, nb, branch))
+            self.bias.copy_(ref.bias)
+        self._register_state_dict_hook(_InceptionFc._fc_slice)
+        self._register_load_state_dict_pre_hook(self._fc_pad)
+
+    def _slots(self, w):
+        return w.view(w.shape[0], self.nb, -1)[:, :, :self.branch]
+
+    @staticmethod
+    def _fc_slice(module, state, prefix, local_metadata):
+        w = state[prefix + "weight"]
+        state[prefix + "weight"] = module._slots(w).reshape(w.shape[0], -1).clone()
+
+    def _fc_pad(self, state, prefix, local_metadata, strict, missing, unexpected, errors):
+        v = state.get(prefix + "weight")
+        if v is not None and v.shape[1] == self.nb * self.branch and v.shape[1] != self.weight.shape[1]:
+            full = torch.zeros(self.weight.shape, dtype=v.dtype, device=v.device)
+            self._slots(full).copy_(v.view(v.shape[0], self.nb, self.branch))
+            state[prefix + "weight"] = full
+
+
+class _InceptionMlp(nn.Module):
+    """`InceptionHead` of SwInception (/root/reference/models/backbones/swinception.py:127-174): the MLP of a Swin block
+    replaced by five convolutional branches on the token volume -- 1x1x1; 1x1x1 -> 3x3x3; -> 3x3x3 twice; -> three times;
+    3x3x3 average pool -> 1x1x1, each conv followed by BatchNorm3d + GELU, int(hidden / 5) output channels per branch and
+    dim // 8 bottleneck channels -- concatenated and projected back by one Linear.  Tokens are channels-last volumes, so
+    the reference's permute / reshape pairs do not exist; the odd channel counts (38 / 6 at dim 48, 153 / 24 at 192 ...)
+    run zero-padded to multiples of 8 (`_PaddedState`), the concat is written slot by slot by the copy form of the
+    interpolation kernel."""
+
+    def __init__(self, dim, hidden, res):
+        super().__init__()
+        self.res = tuple(res)
+        self.branch = int(hidden * 0.2)
+        self.branches = nn.ModuleList([_InceptionBranch(b, dim, self.branch) for b in range(5)])
+        self.fc = _InceptionFc(self.branch, 5, dim)
+        self.sync_group = None
+
+    def run(self, y):
+        outs = [b.run(y, self.sync_group) for b in self.branches]
+        cat = ops.upsample_concat(tuple(y.shape[1:4]), outs)
+        return ops.linear(cat, self.fc.weight, self.fc.bias)
+
+
 class _WindowAttention(nn.Module):
     def __init__(self, dim, ws, heads, qkv_bias):
         super().__init__()
@@ -84,7 +230,12 @@ class _Block(nn.Module):
         self.norm1 = nn.LayerNorm(dim)
         self.attn = _WindowAttention(dim, ws, heads, qkv_bias)
         self.norm2 = nn.LayerNorm(dim)
-        self.mlp = _DepthMlp(dim, int(dim * mlp_ratio)) if mlp == "depth" else _Mlp(dim, int(dim * mlp_ratio))
+        if mlp == "depth":
+            self.mlp = _DepthMlp(dim, int(dim * mlp_ratio))
+        elif mlp == "inception":
+            self.mlp = _InceptionMlp(dim, int(dim * mlp_ratio), self.res)
+        else:
+            self.mlp = _Mlp(dim, int(dim * mlp_ratio))
 
     def _dp_scale(self, x):
         """per-sample stochastic-depth factor mask[b] / keep (models/layers/drop_path.py:15-45), or None; the multiply
@@ -105,7 +256,7 @@ class _Block(nn.Module):
         y = ops.linear(y, a.proj.weight, a.proj.bias)
         x = ops.add(x, y, self._dp_scale(x))
         y = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        if isinstance(self.mlp, _DepthMlp):
+        if isinstance(self.mlp, (_DepthMlp, _InceptionMlp)):
             y = self.mlp.run(y)
         else:
             y = ops.gelu(ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
@@ -201,9 +352,19 @@ class SwinDepth(SwinTransformerNNFormer):
 
     def sync_batchnorm(self, group=True):
         for m in self.modules():
-            if isinstance(m, _DepthMlp):
+            if isinstance(m, (_DepthMlp, _InceptionMlp)):
                 m.sync_group = group
         return self
+
+
+class SwInception(SwinDepth):
+    """/root/reference/models/backbones/swinception.py:609-791 with its default-off extras off (learned class vectors,
+    affine / crop position terms, global token): the reference's Swin encoder whose MLP is the Inception head
+    (`_InceptionMlp`); everything else is SwinTransformerNNFormer.  `sync_batchnorm(group)` as for SwinDepth."""
+
+    def __init__(self, *a, **k):
+        k["mlp"] = "inception"
+        SwinTransformerNNFormer.__init__(self, *a, **k)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -316,6 +316,26 @@ class DwConv3Fn(torch.autograd.Function):
         return dx, None, None
 
 
+class AvgPool3Fn(torch.autograd.Function):
+    """nn.AvgPool3d(kernel_size=3, stride=1, padding=1) (count_include_pad: every window divides by 27) on a token volume:
+    the depthwise k3 kernel with the constant weight 1/27 (/root/reference/models/backbones/swinception.py:113-116); the
+    operator is symmetric, so the input gradient is the same launch on dy."""
+
+    @staticmethod
+    def _taps(x):
+        return torch.full((27, x.shape[-1]), 1.0 / 27.0, dtype=x.dtype, device=x.device)
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        return hip.dwconv3d_k3(x, AvgPool3Fn._taps(x), None, torch.empty_like(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        return hip.dwconv3d_k3(dy, AvgPool3Fn._taps(dy), None, torch.empty_like(dy), flip=True)
+
+
 class BatchNormFn(torch.autograd.Function):
     """nn.BatchNorm3d on a channels-last volume (layers.BatchNormAct: training statistics + running-statistics update,
     eval statistics, optional cross-rank synchronisation); `weight` / `bias` are passed so autograd sees the parameters"""
@@ -442,6 +462,10 @@ def dropout3d(x, p, training, mask=None):
 
 def dwconv3(x, weight, bias=None):
     return DwConv3Fn.apply(x, weight, bias)
+
+
+def avg_pool3(x):
+    return AvgPool3Fn.apply(x)
 
 
 def batch_norm(x, bn, group=None):

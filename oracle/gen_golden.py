@@ -177,6 +177,38 @@ def gen_swindepth():
     _save("swindepth_encoder.npz", **out)
 
 
+def gen_swinception():
+    """the reference's SwInception encoder (models/backbones/swinception.py:609-791; learned class vectors off): Inception
+    head MLP (1x1 / 3x3 / double / triple 3x3 / average-pool branches of Conv3d + BatchNorm3d + GELU, 4- and 25- / 8- and
+    51-channel convs at embed_dim 32) in TRAINING mode, stochastic depth 0; features + gradient probes + running statistics,
+    then the eval-mode features on the updated statistics"""
+    import models.backbones.swinception as SI
+    vol = (24, 24, 24)
+    m = SI.SwInception(pretrain_img_size=vol, patch_size=(2, 2, 2), in_chans=1, embed_dim=32, depths=[2, 2],
+                       num_heads=[2, 4], window_size=[6, 3], drop_path_rate=0.0, use_learned_cls_vectors=False,
+                       out_indices=(0, 1))
+    det_fill_(m, "si")
+    m.train()
+    x = det_tensor("si_x", (2, 1) + vol).requires_grad_(True)
+    outs = m((x, None, None))
+    loss = sum((o * det_tensor(f"si_r{i}", o.shape)).sum() for i, o in enumerate(outs))
+    loss.backward()
+    mlp = m.layers[0].blocks[1].mlp
+    b = mlp.branches
+    out = dict(dx=x.grad, d_b1_w=b[0].branch1x1.conv.weight.grad, d_b3_2_w=b[1].branch3x3_2.conv.weight.grad,
+               d_b5_2_w=b[2].branch3x3dbl_2.conv.weight.grad, d_b7_1_w=b[3].branch3x3trpl_1.conv.weight.grad,
+               d_b7_4_bn_w=b[3].branch3x3trpl_4.bn.weight.grad, d_b7_4_bn_b=b[3].branch3x3trpl_4.bn.bias.grad,
+               d_pool_w=b[4].branch_pool_2.conv.weight.grad, d_fc_w=mlp.fc.weight.grad, d_fc_b=mlp.fc.bias.grad,
+               d_fc_w_l1=m.layers[1].blocks[0].mlp.fc.weight.grad,
+               rm=b[2].branch3x3dbl_3.bn.running_mean, rv=b[2].branch3x3dbl_3.bn.running_var,
+               **{f"out{i}": o for i, o in enumerate(outs)})
+    m.eval()
+    with torch.no_grad():
+        for i, o in enumerate(m((x.detach(), None, None))):
+            out[f"eval{i}"] = o
+    _save("swinception_encoder.npz", **out)
+
+
 def gen_segformer3d():
     """the reference's SegFormer3D (models/backbones/segformer_backbone.py MixVisionTransformer + models/segmentors/
     segformer_head_official.py SegFormerHeadOfficial, wired as model_builder.py:190-205) in TRAINING mode (BatchNorm batch
@@ -423,6 +455,7 @@ def main():
     gen_basic_layer_mask(ref)
     gen_encoder(ref)
     gen_swindepth()
+    gen_swinception()
     gen_segformer3d()
     gen_lr_and_misc()
     gen_unetr_conv_blocks()

@@ -329,6 +329,57 @@ def test_drop_path_residual_add_vs_reference_golden(golden_dir):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swinception_encoder_vs_reference_golden(golden_dir, dtype):
+    """SwInception encoder (Inception-head MLP) against the reference's own
+    models/backbones/swinception.py (tests/golden/swinception_encoder.npz): training-mode features, gradient probes through
+    every branch (4- / 25- / 8- / 51-channel convolutions run zero-padded to multiples of 8), running statistics,
+    eval-mode features; the weights arrive through the reference-shaped state dict"""
+    from medicalsemseg_amd.models.swin_unetr import SwInception
+    from oracle import swin as OW
+    g = _load(golden_dir, "swinception_encoder.npz")
+    vol = (24, 24, 24)
+    ref = OW.SwinTransformerNNFormer(vol, (2, 2, 2), 1, 32, (2, 2), (2, 4), (6, 3), mlp="inception")
+    det_fill_(ref, "si")
+    m = SwInception(vol, (2, 2, 2), 1, 32, (2, 2), (2, 4), (6, 3), drop_path_rate=0.0, compute_dtype=dtype)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).train()
+    x = det_tensor("si_x", (2, 1) + vol).to(DEV)
+    feats, _ = m((x, None, None))
+    tol_f, tol_g = (1e-3, 5e-3) if dtype == torch.float32 else (6e-2, 1.5e-1)   # bf16: drift through 44 BatchNorm stages
+    loss = 0
+    for i, f in enumerate(feats):
+        got = f.permute(0, 4, 1, 2, 3)
+        assert _rel(got, g[f"out{i}"]) < tol_f, f"feature {i}: {_rel(got, g[f'out{i}']):.3e}"
+        loss = loss + (got.float() * det_tensor(f"si_r{i}", g[f"out{i}"].shape).to(DEV)).sum()
+    loss.backward()
+    mlp = m.layers[0].blocks[1].mlp
+    b = mlp.branches
+    fcw = lambda q: q.fc.weight.grad.view(q.fc.weight.shape[0], 5, -1)[:, :, :q.branch].reshape(q.fc.weight.shape[0], -1)
+    probes = {"d_b1_w": b[0].branch1x1.conv.weight.grad[:25, :32], "d_b3_2_w": b[1].branch3x3_2.conv.weight.grad[:25, :4],
+              "d_b5_2_w": b[2].branch3x3dbl_2.conv.weight.grad[:4, :4], "d_b7_1_w": b[3].branch3x3trpl_1.conv.weight.grad[:4, :32],
+              "d_b7_4_bn_w": b[3].branch3x3trpl_4.bn.weight.grad[:25], "d_b7_4_bn_b": b[3].branch3x3trpl_4.bn.bias.grad[:25],
+              "d_pool_w": b[4].branch_pool_2.conv.weight.grad[:25, :32], "d_fc_w": fcw(mlp), "d_fc_b": mlp.fc.bias.grad,
+              "d_fc_w_l1": fcw(m.layers[1].blocks[0].mlp)}
+    errs = {k: _rel(t, g[k]) for k, t in probes.items()}
+    print(f"[{dtype}] SwInception 24^3 gradient errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) < tol_g, errs
+    # every gradient that lands on a padding entry is exactly zero (so the padding stays zero under AdamW)
+    w = b[2].branch3x3dbl_2.conv.weight.grad
+    assert float(w[4:].abs().max()) == 0.0 and float(w[:, 4:].abs().max()) == 0.0
+    assert float(b[3].branch3x3trpl_4.bn.weight.grad[25:].abs().max()) == 0.0
+    assert float(mlp.fc.weight.grad.view(32, 5, -1)[:, :, 25:].abs().max()) == 0.0
+    bn = b[2].branch3x3dbl_3.bn
+    if dtype == torch.float32:
+        assert np.allclose(bn.running_mean[:25].cpu().numpy(), g["rm"], atol=1e-4)
+        assert np.allclose(bn.running_var[:25].cpu().numpy(), g["rv"], atol=1e-4)
+    m.eval()
+    with torch.no_grad():
+        ef, _ = m((x, None, None))
+    for i, f in enumerate(ef):
+        assert _rel(f.permute(0, 4, 1, 2, 3), g[f"eval{i}"]) < tol_f, i
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_swindepth_encoder_vs_reference_golden(golden_dir, dtype):
     """SwinDepth encoder (depthwise-conv + BatchNorm MLP) against the reference's own
     models/backbones/swindepth.py (tests/golden/swindepth_encoder.npz): training-mode features and gradients,

@@ -277,6 +277,38 @@ def test_segformer3d_and_swindepth_state_dict_keys_and_builder():
     assert sorted(net.encoder.state_dict()) == sorted(enc.state_dict())
 
 
+def test_swinception_state_dict_has_reference_shapes_and_round_trips():
+    """product SwInception computes on zero-padded channel counts (multiples of 8) but its state dict shows and accepts the
+    reference's shapes (key layout of oracle/swin.py, which is pinned against the reference file); loading re-zeroes the
+    padding; build_model wires the branch of model_builder.py:67-119"""
+    import argparse
+    from medicalsemseg_amd.models.model_builder import build_model
+    from oracle import swin as OW
+    from tests.golden_util import det_fill_
+    cfg = argparse.Namespace(model="SwInception", vol_size=(24, 24, 24), patch_size=(2, 2, 2), in_chans=1, hidden_dim=32,
+                             depths=[2, 2], num_heads=[2, 4], window_size=[6, 3], qkv_bias=True, mlp_ratio=4.0, output_dim=2,
+                             compute_dtype="f32")
+    net = build_model(cfg)
+    ref = OW.SwinTransformerNNFormer((24, 24, 24), (2, 2, 2), 1, 32, (2, 2), (2, 4), (6, 3), mlp="inception")
+    det_fill_(ref, "si")
+    sd, rd = net.encoder.state_dict(), ref.state_dict()
+    assert sorted(sd) == sorted(rd)
+    assert all(sd[k].shape == v.shape for k, v in rd.items())
+    mlp = net.encoder.layers[0].blocks[1].mlp
+    conv = mlp.branches[2].branch3x3dbl_2.conv            # reference 4 -> 4 channels, computed as 8 -> 8
+    assert tuple(conv.weight.shape) == (8, 8, 3, 3, 3) and tuple(mlp.fc.weight.shape) == (32, 5 * 32)
+    with torch.no_grad():
+        conv.weight.add_(1.0)                               # dirty the padding; a load must restore the zeros
+    net.encoder.load_state_dict(rd)
+    back = net.encoder.state_dict()
+    assert all(torch.equal(back[k], v) for k, v in rd.items())
+    assert float(conv.weight[4:].abs().max()) == 0.0 and float(conv.weight[:, 4:].abs().max()) == 0.0
+    w = mlp.fc.weight.view(32, 5, 32)
+    assert float(w[:, :, 25:].abs().max()) == 0.0 and torch.equal(w[:, :, :25].reshape(32, 125), rd["layers.0.blocks.1.mlp.fc.weight"])
+    bn = mlp.branches[0].branch1x1.bn
+    assert float(bn.weight[25:].abs().max()) == 0.0 and float(bn.bias[25:].abs().max()) == 0.0
+
+
 def test_nifti_writer_round_trip_and_header(tmp_path):
     """NIfTI-1 single-file writer (what nib.save(nib.Nifti1Image(arr, affine)) produces for the reference's test outputs):
     header fields at their specified offsets, Fortran-ordered data, sform = affine, quaternion of a flipped-x affine"""

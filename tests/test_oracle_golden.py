@@ -261,6 +261,38 @@ def test_swindepth_oracle_vs_reference_file(golden_dir):
             assert np.allclose(o.numpy(), g[f"eval{i}"], rtol=1e-3, atol=2e-4), i
 
 
+def test_swinception_oracle_vs_reference_file(golden_dir):
+    """oracle SwInception (oracle/swin.py with the Inception-head MLP: 4- / 25- / 8- / 51-channel Conv3d + BatchNorm3d + GELU
+    branches, average-pool branch, concat + Linear) against the reference's own models/backbones/swinception.py:
+    training-mode features, gradient probes, running statistics, eval-mode features"""
+    g = _load(golden_dir, "swinception_encoder.npz")
+    vol = (24, 24, 24)
+    m = osw.SwinTransformerNNFormer(vol, (2, 2, 2), 1, 32, (2, 2), (2, 4), (6, 3), mlp="inception")
+    det_fill_(m, "si")
+    m.train()
+    x = det_tensor("si_x", (2, 1) + vol).requires_grad_(True)
+    outs = m((x, None, None))
+    for i, o in enumerate(outs):
+        assert np.allclose(o.detach().numpy(), g[f"out{i}"], rtol=1e-3, atol=2e-4), i
+    sum((o * det_tensor(f"si_r{i}", o.shape)).sum() for i, o in enumerate(outs)).backward()
+    mlp = m.layers[0].blocks[1].mlp
+    b = mlp.branches
+    rel = lambda a, c: float(np.abs(a.detach().numpy() - c).max() / max(np.abs(c).max(), 1e-6))
+    probes = dict(dx=x.grad, d_b1_w=b[0].branch1x1.conv.weight.grad, d_b3_2_w=b[1].branch3x3_2.conv.weight.grad,
+                  d_b5_2_w=b[2].branch3x3dbl_2.conv.weight.grad, d_b7_1_w=b[3].branch3x3trpl_1.conv.weight.grad,
+                  d_b7_4_bn_w=b[3].branch3x3trpl_4.bn.weight.grad, d_b7_4_bn_b=b[3].branch3x3trpl_4.bn.bias.grad,
+                  d_pool_w=b[4].branch_pool_2.conv.weight.grad, d_fc_w=mlp.fc.weight.grad, d_fc_b=mlp.fc.bias.grad,
+                  d_fc_w_l1=m.layers[1].blocks[0].mlp.fc.weight.grad)
+    errs = {k: rel(v, g[k]) for k, v in probes.items()}
+    assert max(errs.values()) < 2e-3, errs
+    bn = b[2].branch3x3dbl_3.bn
+    assert np.allclose(bn.running_mean.numpy(), g["rm"], atol=1e-5) and np.allclose(bn.running_var.numpy(), g["rv"], atol=1e-5)
+    m.eval()
+    with torch.no_grad():
+        for i, o in enumerate(m((x.detach(), None, None))):
+            assert np.allclose(o.numpy(), g[f"eval{i}"], rtol=1e-3, atol=2e-4), i
+
+
 def test_segformer3d_oracle_vs_reference_files(golden_dir):
     """oracle/segformer.py against the reference's own MixVisionTransformer + SegFormerHeadOfficial (training-mode logits,
     encoder features, gradient probes, BatchNorm running statistics, eval-mode logits)"""
