@@ -437,10 +437,50 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const ReducePar
     }
 }
 
+// The same sum for conv-layout gradients (dw[m][k][tap] with the taps contiguous, T <= 32): one block per (m, 32-wide k
+// block).  The slab rows [tap][m][k 0..31] are read coalesced (128 B per row and slab), summed over the slabs in slab
+// order (the order of the kernel above: bit-identical results), transposed through LDS and written as ONE contiguous
+// run of 32 x T floats -- the thread-per-output form above writes with a stride of T floats, i.e. one cache line per
+// lane (36 us for the 64 MB gradient of a 768 -> 768 convolution, 14 us for 256 -> 256).
+__global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const ReduceParams p) {
+    __shared__ float tile[32][33];
+    const int m = blockIdx.x, kb = blockIdx.y;
+    const int cbw = p.cbw, T = p.T;
+    const int mb = m / cbw, ml = m - mb * cbw;
+    const long long slabf = (long long)T * cbw * cbw;
+    const int kl = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    const int kbs = kb * 32 / cbw, klo = kb * 32 - kbs * cbw;   // slab k block and offset inside it (cbw = 16: two rows of 16)
+    const int kk = klo + kl, kbb = kbs + kk / cbw, kin = kk % cbw;
+    const float* base = p.slabs + ((long long)(mb * p.kblks + kbb) * p.nslots) * slabf + (long long)ml * cbw + kin;
+    const bool kok = kb * 32 + kl < p.K;
+    for (int t = r0; t < T; t += 8) {
+        float s = 0.f;
+        if (kok) {
+            const float* src = base + (long long)t * cbw * cbw;
+#pragma unroll 8
+            for (int sl = 0; sl < p.nslots; ++sl) s += src[(long long)sl * slabf];
+        }
+        tile[t][kl] = s;
+    }
+    __syncthreads();
+    const int nk = min(32, p.K - kb * 32);
+    float* dst = p.dw + (long long)m * p.s_m0 + (long long)kb * 32 * T;
+    for (int o = threadIdx.x; o < nk * T; o += 256) {
+        const int k = o / T, t = o - k * T;
+        dst[o] = p.accumulate ? dst[o] + tile[t][k] : tile[t][k];
+    }
+}
+
 int launch_reduce(const ReduceParams& rp, hipStream_t stream) {
     const long long total = (long long)rp.M * rp.T * rp.K;
     if (total >= 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "wgrad: weight tensor too large");
-    if (rp.nslots <= 32) {
+    // conv layout: dw[m][k][tap], taps contiguous, no two-level channel index
+    const bool conv_layout = rp.s_t == 1 && rp.s_k0 == rp.T && rp.K0 == rp.K && rp.M0 == rp.M && rp.T > 1 && rp.T <= 32 &&
+                             rp.s_m0 == (long long)rp.K * rp.T && (rp.cbw == 32 || rp.cbw == 16);
+    static const bool no_rows = getenv("MSSEG_NO_REDUCE_ROWS") != nullptr;   // A/B switch
+    if (rp.nslots <= 32 && conv_layout && !no_rows && ceil_div(rp.K, 32) <= 65535) {
+        hipLaunchKernelGGL(wgrad_reduce_rows_kernel, dim3(rp.M, ceil_div(rp.K, 32)), dim3(256), 0, stream, rp);
+    } else if (rp.nslots <= 32) {
         int rb = (int)((total + 255) / 256);
         if (rb > 8192) rb = 8192;
         hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3(rb), dim3(256), 0, stream, rp);
@@ -472,6 +512,11 @@ int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes
     const int wave_slots = 1;   // one slab per workgroup (the flat kernels add their four waves through LDS)
     const size_t slab_bytes = (size_t)C::SLAB_FLOATS * 4;
     long long gx = msseg_num_cus() * ((C::LDS_BYTES > 80 * 1024) ? 1 : 2);
+    // Small grids (the 24^3 ... 6^3 levels): every workgroup writes a 110 KB slab whatever it computed, so a full chip
+    // of workgroups moves 56 MB of slabs (written, then read by the reduction) for a few GFLOP.  Half a workgroup per CU
+    // measured fastest there (sweep 64 ... 512 in profiles/README.md): 30-34 -> 21-25 us per layer.
+    static const int wgs_env = getenv("MSSEG_WG_TOTAL") ? atoi(getenv("MSSEG_WG_TOTAL")) : 0;   // A/B: total workgroups
+    if (NTAPS == 27 && (long long)p.ntiles * pairs <= 4LL * msseg_num_cus()) gx = wgs_env > 0 ? wgs_env : msseg_num_cus() / 2;
     if (pairs > 1) gx = (gx + pairs - 1) / pairs;
     if (gx > p.ntiles) gx = p.ntiles;
     const long long fit = (long long)(ws_bytes / (slab_bytes * pairs * wave_slots));
@@ -496,7 +541,10 @@ template <typename T> int launch_wg_k3(WgradParams& p, ReduceParams& rp, void* w
         K3WgParams pp{};
         pp.pten = p.pten; pp.ldp = p.ldp; pp.qten = p.qten; pp.ldq = p.ldq;
         pp.N = p.N; pp.D = p.D; pp.H = p.H; pp.W = p.W; pp.M = p.M; pp.K = p.K; pp.kblks = ceil_div(p.K, 32);
-        if (msseg_k3wg_pp_eligible(pp)) {
+        // grids below 8 voxels per axis fill a quarter of the ping-pong kernel's 4x4x16 tiles: generic kernel (2x4x8 tiles)
+        static const int pp_min_dim = getenv("MSSEG_K3WG_MINDIM") ? atoi(getenv("MSSEG_K3WG_MINDIM")) : 8;   // A/B
+        const int mnd = p.D < p.H ? (p.D < p.W ? p.D : p.W) : (p.H < p.W ? p.H : p.W);
+        if (mnd >= pp_min_dim && msseg_k3wg_pp_eligible(pp)) {
             const int pairs = ceil_div(p.M, 32) * ceil_div(p.K, 32);
             int gx = msseg_k3wg_pp_grid(pp);
             const long long fit = (long long)(wsb / ((size_t)27 * 32 * 32 * 4 * pairs));
