@@ -737,6 +737,14 @@ int launch_nt(IgemmParams& p, hipStream_t stream) {
 static void k3_plan(int N, int D, int H, int W, int M, int* cfg, int* cb) {
     const int mn = D < H ? (D < W ? D : W) : (H < W ? H : W);
     const int std_cb = msseg_cout_block(M);
+    {   // tuning override for grids below 32 voxels per axis: MSSEG_K3_FORCE="<cfg 1|2>,<cout block 16|32>"
+        static const char* force = getenv("MSSEG_K3_FORCE");
+        if (force && mn < 32 && std_cb == 32) {
+            *cfg = force[0] - '0';
+            *cb = atoi(force + 2);
+            return;
+        }
+    }
     const long long want = (long long)msseg_num_cus() * 3 / 4;
     auto wgs = [&](int td, int th, int tw, int c) {
         return (long long)N * ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw) * ceil_div(M, c);
