@@ -156,6 +156,11 @@ class _WgradSide:
         right away (small layers); DEFER: collected and issued to the side stream by flush() -- full-chip wgrads that
         should run under the small kernels of the deep levels rather than against the next full-chip dgrad."""
         if self.active is not None:
+            if mode == self.INLINE and self.mode != self.INLINE:
+                # back on the calling stream: its weight-gradient launches share the slab workspace with the side
+                # stream's, so everything issued there must have finished first
+                self.flush()
+                torch.cuda.current_stream().wait_stream(self.active)
             self.mode = mode
 
     def _issue(self, fn):

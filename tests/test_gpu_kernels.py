@@ -51,6 +51,8 @@ def gen(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("cin,cout,sp", [(32, 32, (16, 16, 16)), (64, 32, (32, 32, 32)), (32, 64, (12, 12, 12)),
                                          (48, 48, (12, 12, 24)), (16, 16, (8, 8, 8)), (128, 256, (6, 6, 6)),
                                          (96, 48, (6, 10, 18)), (8, 24, (5, 7, 9)),
+                                         # small grids, two channel blocks per stage: odd block counts (3, 5), a partial last block
+                                         (96, 64, (6, 10, 18)), (160, 32, (8, 8, 8)), (72, 32, (12, 12, 12)),
                                          # grids large enough for the ping-pong kernel (bf16, 32 channels per stage)
                                          (32, 32, (32, 48, 64)), (32, 64, (30, 29, 70)), (64, 32, (34, 31, 50)),
                                          # 48-channel layers (Swin-UNETR decoder): partial 32-blocks in the ping-pong wgrad
