@@ -124,7 +124,7 @@ def test_build_model_surface():
     n_enc = sum(p.numel() for p in sw.encoder.parameters())
     assert n_enc == 15362430, n_enc   # the reference encoder's parameter count
     with pytest.raises(NotImplementedError):
-        build_model(get_args("--model SwInception".split()))
+        build_model(get_args("--model FocalNetUNETR".split()))
     with pytest.raises(ValueError):
         build_model(get_args([]))   # the reference's default 'UNETR_Official' matches no branch either
 
