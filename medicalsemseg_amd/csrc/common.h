@@ -118,16 +118,18 @@ MSSEG_DEVFN bool grid_last_block(unsigned int* counter, unsigned int total_block
 // every thread with up to 8 independent loads in flight, row slots then combined through LDS in a fixed order
 // (bit-reproducible).  The L totals end up in lds[NT * 4 ..]; lds: >= NT * 4 + L floats, 16-byte aligned.
 template <int NT>
-MSSEG_DEVFN void block_rows_sum(const float* rows, int R, int L, float* lds) {
+MSSEG_DEVFN void block_rows_sum(const float* rows, int R, int L, float* lds, long long stride = 0) {
+    // stride: distance between rows in floats (a multiple of 4; 0 = L): sums an L-wide column slice of wider rows
     const int tid = threadIdx.x, q = L >> 2;
     const int SL = NT / q;
     const int c4 = tid % q, slot = tid / q;
+    const long long q_stride = (stride ? stride : (long long)L) >> 2;
     f32x4_t* l4 = (f32x4_t*)lds;
     if (slot < SL) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         const f32x4_t* src = (const f32x4_t*)rows + c4;
 #pragma unroll 8
-        for (int x = slot; x < R; x += SL) acc += src[(long long)x * q];
+        for (int x = slot; x < R; x += SL) acc += src[(long long)x * q_stride];
         l4[slot * q + c4] = acc;
     }
     __syncthreads();

@@ -235,6 +235,11 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
     // relative to the tile origin and its halo coordinates are computed once (VALU work per tile drops from ~40 to
     // ~3 instructions per chunk; interior tiles skip the bounds checks altogether).
     int a_rel[NIT_A];
+    // small tiles also keep the packed halo coordinates (hd | hh << 8 | hw << 16): on the 24^3 ... 6^3 grids nearly every
+    // tile is an edge tile and the bounds test runs inside the MFMA loop on one wave per SIMD, where recomputing the
+    // coordinates (two divisions by constants per chunk) is exposed latency; the large tiles (NIT_A up to 17) recompute
+    constexpr bool KEEP_PK = SRC == SRC_DIRECT && NIT_A <= 8;
+    int a_pk[KEEP_PK ? NIT_A : 1];
     const int XD = STRIDE == 1 ? p.D : p.ID, XH = STRIDE == 1 ? p.H : p.IH, XW = STRIDE == 1 ? p.W : p.IW;
     if constexpr (SRC == SRC_DIRECT) {
 #pragma unroll
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
             const int cq = i & 3, hv = i >> 2;
             const int hw = hv % PW, t2 = hv / PW, hh = t2 % PH, hd = t2 / PH;
             a_rel[it] = (int)((((long long)hd * XH + hh) * XW + hw) * p.ldx) + cq * EPC;
+            if constexpr (KEEP_PK) a_pk[it] = hd | (hh << 8) | (hw << 16);
         }
     }
     // The global loads of a stage are issued one at a time (fetch_a / fetch_b) from slots spread over the MFMA loop
@@ -271,10 +277,16 @@ __global__ __launch_bounds__(WAVES * 64, (NSL > 1 ? 2 : 1)) void igemm_fwd_kerne
         if constexpr (SRC == SRC_DIRECT) {
             if (p.rel32_ok) {
                 bool ok = f_cok && i < HV * 4;
-                if (!f_interior) {   // edge tile: recompute this chunk's halo coordinates (kept out of registers)
-                    const int hv = i >> 2;
-                    const int hw = hv % PW, t2 = hv / PW;
-                    const int d = f_dB + t2 / PH, h = f_hB + t2 % PH, w = f_wB + hw;
+                if (!f_interior) {   // edge tile
+                    int d, h, w;
+                    if constexpr (KEEP_PK) {
+                        const int pk = a_pk[it];
+                        d = f_dB + (pk & 255); h = f_hB + ((pk >> 8) & 255); w = f_wB + (pk >> 16);
+                    } else {         // recompute this chunk's halo coordinates (kept out of registers)
+                        const int hv = i >> 2;
+                        const int hw = hv % PW, t2 = hv / PW;
+                        d = f_dB + t2 / PH; h = f_hB + t2 % PH; w = f_wB + hw;
+                    }
                     ok = ok && (unsigned)d < (unsigned)XD && (unsigned)h < (unsigned)XH && (unsigned)w < (unsigned)XW;
                 }
                 pa[it] = ok ? *(const u32x4_t*)(f_bp + a_rel[it]) : u32x4_t{0u, 0u, 0u, 0u};
@@ -652,15 +664,22 @@ __global__ __launch_bounds__(256) void k3_stats_finalize_kernel(const K3FinParam
     __shared__ __attribute__((aligned(16))) float fin[256 * 4 + 8 * 48 * 2];
     const int tid = threadIdx.x;
     const int L = f.N * f.coutb * 2;
-    block_rows_sum<256>(f.ws + (long long)blockIdx.x * f.R * L, f.R, L, fin);
-    const float* tot = fin + 256 * 4;   // [n][cl][2]
     const int cbase = blockIdx.x * f.coutb;
     if (f.nb_stats == nullptr) {
-        for (int i = tid; i < L; i += 256) {
-            const int n = i / (f.coutb * 2), cl = (i % (f.coutb * 2)) >> 1, k = i & 1;
+        // forward statistics: one block per (cout block, sample) sums that sample's column slice of the partial rows
+        // (with one block per cout block a thread walked 64 ... 128 rows: 5 us at N = 2, 8 us at N = 8)
+        const int n = blockIdx.y, Ls = f.coutb * 2;
+        block_rows_sum<256>(f.ws + (long long)blockIdx.x * f.R * L + n * Ls, f.R, Ls, fin, L);
+        const float* tot = fin + 256 * 4;   // [cl][2]
+        for (int i = tid; i < Ls; i += 256) {
+            const int cl = i >> 1, k = i & 1;
             if (cbase + cl < f.M) f.stats[((long long)n * f.M + cbase + cl) * 2 + k] = tot[i];
         }
-    } else if (tid < f.coutb && cbase + tid < f.M) {
+        return;
+    }
+    block_rows_sum<256>(f.ws + (long long)blockIdx.x * f.R * L, f.R, L, fin);
+    const float* tot = fin + 256 * 4;   // [n][cl][2]
+    if (tid < f.coutb && cbase + tid < f.M) {
         // sum dz*xhat = rstd * (sum dz*yraw - mean * sum dz); dbeta / dgamma = sums over the samples
         const int cg = cbase + tid;
         float g0 = 0.f, g1 = 0.f;
@@ -805,7 +824,7 @@ int check_common(const void* x, long long ldx, const void* wp, const void* y, lo
 }  // namespace
 
 int msseg_k3_stats_finalize(const K3FinParams& f, int ncb, hipStream_t stream) {
-    hipLaunchKernelGGL(k3_stats_finalize_kernel, dim3(ncb), dim3(256), 0, stream, f);
+    hipLaunchKernelGGL(k3_stats_finalize_kernel, dim3(ncb, f.nb_stats ? 1 : f.N), dim3(256), 0, stream, f);
     MSSEG_CHECK_LAUNCH("k3_stats_finalize");
     return MSSEG_OK;
 }
