@@ -262,11 +262,11 @@ def bench_sliding_window(args, dev, dtype, world, rank):
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "launch": "hipGraph replay of the window forward",
                "config": {"workload": w["name"].format(c=args.classes, v=args.sw_size, s=args.size, w=n_win, b=args.sw_batch),
                           "parallelism": f"window batches round-robin over {world} rank(s)" + (
-                              ", one all-gather of logits per step" if world > 1 else ""),
+                              ", one all-gather of compact logits per step, under the next step's forward" if world > 1 else ""),
                           "windows_per_rank": [sum(1 for s in range(nsteps) for j in range(args.sw_batch)
                                                    if (s * world + r) * args.sw_batch + j < n_win) for r in range(world)],
                           "all_gather_bytes_per_rank_per_volume": (0 if world == 1 else
-                              nsteps * world * args.sw_batch * args.size ** 3 * LOGIT_LD * (2 if args.dtype == "bf16" else 4)),
+                              nsteps * world * args.sw_batch * args.size ** 3 * args.classes * (2 if args.dtype == "bf16" else 4)),
                           "out_mean": round(float(out.mean()), 5)}}
         scale = (args.sw_size / 512.0) ** 3
         res["model_tflops"] = round(value * w["gflop_per_vol"] * n_win / 1000.0 / 1e3, 2)

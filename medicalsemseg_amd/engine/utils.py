@@ -198,7 +198,20 @@ def sliding_window_inference(inputs: torch.Tensor, affine, roi_size, sw_batch_si
         g = _GraphedInfer.get(predictor, nb, Cin, roi, dev)
         from .. import layers
         layers.PACK_REGISTRY.refresh_if_stale(dev)    # parameters may have changed since the graph was captured
-        out, cnt = accumulators(predictor.out_channels)
+        ncls = predictor.out_channels
+        out, cnt = accumulators(ncls)
+        # Sharded: the step's logits are exchanged as COMPACT channels-first rows (ncls of the 8 channels of a 16-byte
+        # logits row are real: 6 instead of 16 bytes per voxel on the links at 3 classes) and the all-gather of step i
+        # runs under the forward of step i + 1 (two buffer pairs; the blend of a step follows its exchange, one step
+        # late, in the same global window order -> still bit-identical to the single-rank result).
+        comp = gath = None
+        pending = None                                    # (work handle, gathered buffer, step) of the exchange in flight
+
+        def blend_step(item):
+            work, buf, step = item
+            work.wait()
+            hip.sw_blend_batch(buf, imp, out, cnt, rows_blend[step * ws * nb:(step + 1) * ws * nb], ws * nb)
+
         for i in range(nsteps):
             g0 = (i * ws + rk) * nb                       # this rank's batch of the step (all slots unused: idle replay)
             hip.sw_gather_batch(vol, g.win, rows_gather[g0:g0 + nb], nb, cval, channels_last_ld=Cin)
@@ -206,11 +219,16 @@ def sliding_window_inference(inputs: torch.Tensor, affine, roi_size, sw_batch_si
             if ws == 1:
                 hip.sw_blend_batch(seg, imp, out, cnt, rows_blend[g0:g0 + nb], nb, channels_last_ld=seg.shape[-1])
                 continue
-            if gathered is None:
-                gathered = torch.empty((ws * nb,) + tuple(seg.shape[1:]), dtype=seg.dtype, device=dev)
-            torch.distributed.all_gather_into_tensor(gathered, seg)
-            hip.sw_blend_batch(gathered, imp, out, cnt, rows_blend[i * ws * nb:(i + 1) * ws * nb], ws * nb,
-                               channels_last_ld=seg.shape[-1])
+            if comp is None:
+                comp = [torch.empty((nb, ncls) + tuple(seg.shape[1:4]), dtype=seg.dtype, device=dev) for _ in range(2)]
+                gath = [torch.empty((ws * nb, ncls) + tuple(seg.shape[1:4]), dtype=seg.dtype, device=dev) for _ in range(2)]
+            hip.to_channels_first(seg[..., :ncls], comp[i & 1])
+            work = torch.distributed.all_gather_into_tensor(gath[i & 1], comp[i & 1], async_op=True)
+            if pending is not None:
+                blend_step(pending)
+            pending = (work, gath[i & 1], i)
+        if pending is not None:
+            blend_step(pending)
     else:
         win = None
         ncls = int(getattr(predictor, "out_channels", 0) or 0)
