@@ -66,6 +66,51 @@ def test_engine_loops_on_gpu():
     assert set(v) >= {"val/loss", "val/mDice"} and np.isfinite(v["val/loss"])
 
 
+def test_swinception_trains_through_the_engine_and_padding_stays_zero():
+    """cfg.model == 'SwInception' through build_model / train_one_epoch (hipGraph replay): the loss falls, the zero-padded
+    channel entries of the Inception head (models/swin_unetr.py `_PaddedState`) are still exactly zero after AdamW steps with
+    weight decay and gradient clipping, and the state dict keeps the reference's shapes"""
+    from medicalsemseg_amd.data import SyntheticLoader
+    from medicalsemseg_amd.engine.train import train_one_epoch
+    from medicalsemseg_amd.losses import DiceCELoss
+    from medicalsemseg_amd.models.model_builder import build_model
+    from medicalsemseg_amd.models.swin_unetr import _BasicConv3d, _InceptionFc
+    from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay
+    from medicalsemseg_amd.utils.arguments import get_args
+    cfg = get_args("--model SwInception --output_dim 2 --vol_size 48 --patch_size 2 --hidden_dim 32 --depths 2 2 --num_heads 2 4 "
+                   "--window_size 6 3 --qkv_bias --gradient_clipping 1.0".split())
+    torch.manual_seed(0)
+    model = build_model(cfg).to(DEV)
+    opt = FlatAdamW(add_weight_decay(model, 1e-2), lr=2e-3, betas=(0.9, 0.95), eps=1e-6)
+    crit = DiceCELoss()
+    scaler = torch.amp.GradScaler("cuda", enabled=False)
+    loader = SyntheticLoader(5, 2, 48, 1, 2, seed=1)
+    s0 = train_one_epoch(model, loader, opt, crit, torch.device(DEV), 0, scaler, cfg)
+    s1 = train_one_epoch(model, loader, opt, crit, torch.device(DEV), 1, scaler, cfg)
+    assert np.isfinite(s1["train/loss"]) and s1["train/loss"] < s0["train/loss"]
+    checked = 0
+    for m in model.modules():
+        if isinstance(m, _BasicConv3d):
+            own = dict(m.named_parameters()); own.update(dict(m.named_buffers()))
+            for name, real in m._real.items():
+                if name.startswith("bn.running"):
+                    continue                     # running statistics of a padding channel are (0, decaying 1): sliced off on save
+                t = own[name].detach().clone()
+                t[tuple(slice(0, n) for n in real)] = 0
+                assert float(t.abs().max()) == 0.0, name
+                checked += 1
+        elif isinstance(m, _InceptionFc):
+            w = m.weight.detach().view(m.weight.shape[0], m.nb, -1)
+            assert w.shape[2] == (m.branch + 7) // 8 * 8
+            if w.shape[2] > m.branch:
+                assert float(w[:, :, m.branch:].abs().max()) == 0.0
+            checked += 1
+    assert checked > 40
+    sd = model.state_dict()
+    assert tuple(sd["encoder.layers.0.blocks.0.mlp.branches.1.branch3x3_2.conv.weight"].shape) == (25, 4, 3, 3, 3)
+    assert tuple(sd["encoder.layers.1.blocks.1.mlp.fc.weight"].shape) == (64, 5 * 51)
+
+
 def test_train_epoch_graph_replay_equals_eager(monkeypatch):
     """the hipGraph replay of forward+loss+backward inside train_one_epoch is the eager step, launch for launch"""
     from medicalsemseg_amd.data import SyntheticLoader
