@@ -960,6 +960,9 @@ int msseg_conv3d_k1_fwd(const void* x, long long ldx, const void* wp, const floa
     if (rc) return rc;
     if (NV < 1 || NV > 0x7fffffffLL || Cin < 1 || Cout < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1: bad shape");
     if (Cin % (16 / esz)) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k1: Cin=%d must be a multiple of %d", Cin, 16 / esz);
+    // many tokens, few channels (the first Swin stage's Linear layers): register-resident-weight streaming kernel
+    if (msseg_linear_regw_eligible(dtype, NV, Cin, Cout, x, ldx, y, ldy, bias))
+        return msseg_linear_regw_launch(x, ldx, wp, bias, y, ldy, NV, Cin, Cout, (hipStream_t)stream);
     IgemmParams p{};
     p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy;
     p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = Cin; p.M = Cout;

@@ -81,3 +81,9 @@ int msseg_deconv2_bwd_launch(const void* dy, long long lddy, const void* wp, voi
                              const float* fwd_stats, float slope, float eps, float* red, float* dgamma, float* dbeta,
                              int accumulate, float* dbias, int dbias_accumulate, void* scratch, size_t scratch_bytes,
                              hipStream_t stream);
+
+// ---- Linear / 1x1x1 conv on many tokens with few channels, register-resident weights (linear_regw.hip) ----
+bool msseg_linear_regw_eligible(int dtype, long long NV, int Cin, int Cout, const void* x, long long ldx, const void* y,
+                                long long ldy, const float* bias);
+int msseg_linear_regw_launch(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                             long long NV, int Cin, int Cout, hipStream_t stream);

@@ -1,0 +1,146 @@
+// Linear / 1x1x1 convolution on many tokens with few channels (bf16): register-resident-weight streaming kernel for gfx950.
+//
+//   y[v][m] = sum_k W[m][k] * x[v][k] + b[m]         v over N*D*H*W voxels (tokens), channels-last rows
+//
+// Replaces nn.Linear in the first Swin stage -- qkv / proj / fc1 / fc2 of
+// /root/reference/models/backbones/swin_nnformer.py:24-42,128-196 on 2 x 48^3 = 221 k tokens with 48 ... 192 channels -- and
+// its input gradient (the same GEMM on the transposed weight image).  These layers are pure bandwidth (85-106 MB in + out
+// for 1-2 GFLOP); the generic implicit-GEMM kernel (igemm_fwd.hip: LDS-staged 256-voxel tiles, one wave per SIMD) ran
+// them at about 1 TB/s.  Same scheme as deconv_k2s2.hip: the whole weight matrix (<= 24 MFMA A fragments) lives in
+// registers for the life of the kernel; a wave takes 16 consecutive tokens, loads its B operand straight from global
+// memory (the channels-last row IS the operand layout: 8 channels of token r per lane quarter), issues NH x KS MFMAs,
+// transposes the 16 x M outputs through a wave-private LDS tile and writes the rows as fully coalesced 16-byte stores.
+#include "k3pp.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int LR_THREADS = 256;
+
+struct LinParams {
+    const void* x; long long ldx;
+    const void* wp;                  // msseg_pack_weights image, T = 1: [cout block][k block][quarter][cout][16 B]
+    const float* bias;
+    void* y; long long ldy;
+    long long NV;
+    int K, cb;                       // logical input channels, cout block width of the image
+};
+
+MSSEG_DEVFN u32x4_t ldg16(const void* p) { return *(const u32x4_t*)p; }
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+MSSEG_DEVFN unsigned pack_bf16x2(float a, float b) {
+    const bf16x2_t v = {(bf16_t)a, (bf16_t)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int KS, int NH>   // KS = ceil(K / 32) k-steps, NH = M / 16 output tiles
+__global__ __launch_bounds__(LR_THREADS, 2) void linear_regw_kernel(const LinParams p) {
+    constexpr int M = NH * 16;
+    constexpr int RSB = M * 2 + 16;                    // LDS bytes per token row (16-byte pad: fewer write conflicts)
+    constexpr int CPV = M * 2 / 16;                    // 16-byte chunks per output row
+    constexpr int TILE_B = 16 * RSB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TILE_B];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    unsigned char* tile = lds + wave * TILE_B;
+    const bf16_t* __restrict__ xg = (const bf16_t*)p.x;
+    bf16_t* __restrict__ yg = (bf16_t*)p.y;
+
+    u32x4_t af[NH][KS];
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int m0 = j * 16;
+            const int blk = m0 / p.cb, row = m0 - blk * p.cb + r;
+            af[j][k] = ldg16((const unsigned char*)p.wp + ((((long long)blk * KS + k) * 4 + q) * p.cb + row) * 16);
+        }
+    f32x4_t bv[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        bv[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv[j] = *(const f32x4_t*)(p.bias + j * 16 + q * 4);
+    }
+    bool kok[KS];                                       // this lane's chunk of k-step k lies inside the row
+#pragma unroll
+    for (int k = 0; k < KS; ++k) kok[k] = k * 32 + q * 8 < p.K;
+
+    const long long groups = (p.NV + 15) >> 4;
+    const long long wstride = (long long)gridDim.x * 4;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += wstride) {
+        const long long v0 = g * 16, v = v0 + r;
+        const bool valid = v < p.NV;
+        u32x4_t bx[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+            bx[k] = (valid && kok[k]) ? ldg16(xg + v * p.ldx + k * 32 + q * 8) : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            f32x4_t acc = bv[j];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) mma_chunk<bf16_t>(acc, af[j][k], bx[k]);
+            const u32x2_t o = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
+            *(u32x2_t*)(tile + r * RSB + (j * 16 + q * 4) * 2) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: LDS ops of one wave execute in order
+        const int nv = (p.NV - v0) < 16 ? (int)(p.NV - v0) : 16;
+#pragma unroll
+        for (int it = 0; it < (16 * CPV + 63) / 64; ++it) {
+            const int ch = it * 64 + lane;
+            const int vv = ch / CPV, part = ch - vv * CPV;
+            if (ch < 16 * CPV && vv < nv) {
+                const u32x4_t o = *(const u32x4_t*)(tile + vv * RSB + part * 16);
+                *(u32x4_t*)(yg + (v0 + vv) * p.ldy + part * 8) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next group's writes
+    }
+}
+
+template <int KS, int NH> int launch(const LinParams& p, hipStream_t stream) {
+    const long long groups = (p.NV + 15) >> 4;
+    long long gx = (groups + 3) / 4;
+    const long long cap = (long long)msseg_num_cus() * 2;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL((linear_regw_kernel<KS, NH>), dim3((unsigned)gx), dim3(LR_THREADS), 0, stream, p);
+    MSSEG_CHECK_LAUNCH("linear_regw");
+    return MSSEG_OK;
+}
+
+}  // namespace
+
+// shapes with an instantiation: (k-steps, output tiles) of the first Swin stage at widths 48 / 144 / 192 and their
+// transposes; everything else stays on the generic kernel
+static bool lr_shape(int Cin, int Cout, int* ks, int* nh) {
+    if (Cout % 16 || Cin % 8) return false;
+    *ks = (Cin + 31) / 32;
+    *nh = Cout / 16;
+    const int k = *ks, n = *nh;
+    return (k == 2 && (n == 3 || n == 9 || n == 12)) || (n == 3 && (k == 5 || k == 6));
+}
+
+bool msseg_linear_regw_eligible(int dtype, long long NV, int Cin, int Cout, const void* x, long long ldx, const void* y,
+                                long long ldy, const float* bias) {
+    static const bool off = getenv("MSSEG_NO_LINEAR_REGW") != nullptr;   // A/B switch
+    int ks, nh;
+    if (off || dtype != MSSEG_BF16 || NV < 16384 || !lr_shape(Cin, Cout, &ks, &nh)) return false;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (ldx % 8) || (ldy % 8) || ldx < Cin || ldy < Cout) return false;
+    if (bias && ((uintptr_t)bias & 15)) return false;
+    return true;
+}
+
+int msseg_linear_regw_launch(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                             long long NV, int Cin, int Cout, hipStream_t stream) {
+    LinParams p{};
+    p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy; p.NV = NV; p.K = Cin;
+    p.cb = msseg_cout_block(Cout);
+    int ks, nh;
+    if (!lr_shape(Cin, Cout, &ks, &nh)) MSSEG_FAIL(MSSEG_EINVAL, "linear_regw: shape %d -> %d has no instantiation", Cin, Cout);
+    if (ks == 2 && nh == 3) return launch<2, 3>(p, stream);
+    if (ks == 2 && nh == 9) return launch<2, 9>(p, stream);
+    if (ks == 2 && nh == 12) return launch<2, 12>(p, stream);
+    if (ks == 5 && nh == 3) return launch<5, 3>(p, stream);
+    return launch<6, 3>(p, stream);
+}

@@ -631,6 +631,39 @@ def test_conv3d_k1_head(dtype, cin, cout):
     assert bool((buf[..., cout:] == 7.0).all())          # the padding channels are not touched
 
 
+@pytest.mark.parametrize("cin,cout", [(48, 144), (48, 48), (48, 192), (192, 48), (144, 48), (40, 48)])
+@pytest.mark.parametrize("tokens", [(2, 24, 24, 32), (1, 25, 27, 29)])
+def test_linear_many_tokens_register_weight_kernel(cin, cout, tokens):
+    """nn.Linear on >= 16 k tokens with the first Swin stage's widths (bf16): `linear_regw_kernel` (weights in registers,
+    operand straight from global, LDS-transposed coalesced rows) for the forward and, through the transposed weight image,
+    the input gradient; a token count that is no multiple of 16, a partial last 32-channel step (48, 144, 40 channels),
+    output rows inside a wider buffer; vs F.linear on the rounded operands (fp32 accumulation)"""
+    from medicalsemseg_amd import hip, ops
+    dev, dtype = _dev(), torch.bfloat16
+    x = gen(*tokens, cin, seed=51)
+    w = gen(cout, cin, seed=52, scale=cin ** -0.5)
+    b = gen(cout, seed=53)
+    xr, wr = rnd(dtype, x, w)
+    xr.requires_grad_(True); wr.requires_grad_(True)
+    yref = F.linear(xr, wr, b)
+    dy = gen(*yref.shape, seed=54)
+    dyr = rnd(dtype, dy)
+    yref.backward(dyr)
+    xg = x.to(dev, dtype).requires_grad_(True)
+    wp, bp = torch.nn.Parameter(w.to(dev)), torch.nn.Parameter(b.to(dev))
+    y = ops.linear(xg, wp, bp)
+    y.backward(dy.to(dev, dtype))
+    check(y.detach(), yref.detach(), dtype, "linear fwd")
+    check(xg.grad, xr.grad, dtype, "linear dgrad")
+    check(wp.grad, wr.grad, dtype, "linear wgrad")
+    # rows inside a wider buffer (ld > channels), no bias
+    wide = torch.full(tokens + (cout + 16,), 3.0, dtype=dtype, device=dev)
+    wpk = hip.pack_conv_k1(w.to(dev), dtype)
+    hip.conv3d_k1(xg.detach(), wpk, None, wide[..., :cout], cin, cout)
+    check(wide[..., :cout], F.linear(xr.detach(), wr.detach()), dtype, "linear fwd into a view")
+    assert bool((wide[..., cout:] == 3.0).all())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout", [(32, 3), (48, 2), (64, 4)])
 def test_conv3d_k1_head_dgrad_inbwd(dtype, cin, cout):
