@@ -2,14 +2,18 @@
 //
 //   y[v][m] = sum_k W[m][k] * x[v][k] + b[m]         v over N*D*H*W voxels (tokens), channels-last rows
 //
-// Replaces nn.Linear in the first Swin stage -- qkv / proj / fc1 / fc2 of
-// /root/reference/models/backbones/swin_nnformer.py:24-42,128-196 on 2 x 48^3 = 221 k tokens with 48 ... 192 channels -- and
-// its input gradient (the same GEMM on the transposed weight image).  These layers are pure bandwidth (85-106 MB in + out
-// for 1-2 GFLOP); the generic implicit-GEMM kernel (igemm_fwd.hip: LDS-staged 256-voxel tiles, one wave per SIMD) ran
-// them at about 1 TB/s.  Same scheme as deconv_k2s2.hip: the whole weight matrix (<= 24 MFMA A fragments) lives in
-// registers for the life of the kernel; a wave takes 16 consecutive tokens, loads its B operand straight from global
-// memory (the channels-last row IS the operand layout: 8 channels of token r per lane quarter), issues NH x KS MFMAs,
-// transposes the 16 x M outputs through a wave-private LDS tile and writes the rows as fully coalesced 16-byte stores.
+// Replaces nn.Linear in the Swin stages -- qkv / proj / fc1 / fc2 of
+// /root/reference/models/backbones/swin_nnformer.py:24-42,128-196: 221 k tokens x 48 ... 192 channels in the first stage,
+// 27 k x 96 ... 384, 3.4 k x 192 ... 768, 432 x 384 below -- and its input gradient (the same GEMM on the transposed weight
+// image).  The first stage is pure bandwidth (85-106 MB in + out for 1-2 GFLOP), the deeper ones are launch-sized; the
+// generic implicit-GEMM kernel (igemm_fwd.hip: LDS-staged 256-voxel tiles, one 32-channel stage after the other on one
+// wave per SIMD) ran the former at about 1 TB/s and the latter at a 30 us floor.  Same scheme as deconv_k2s2.hip: the
+// weights of a workgroup's output slice (<= 24 MFMA A fragments per lane) live in registers for the life of the kernel;
+// a wave takes 16 consecutive tokens, loads its B operand straight from global memory (the channels-last row IS the
+// operand layout: 8 channels of token r per lane quarter), issues NH x KS MFMAs, transposes the 16 x M outputs through a
+// wave-private LDS tile and writes the rows as coalesced 16-byte stores.  grid.y slices the output channels: workgroup
+// (x, s) computes channels s * NH * 16 .. of its tokens, so that a wide layer's weights still fit the register file and
+// a short token list still fills the chip.
 #include "k3pp.h"
 
 #include <stdlib.h>
@@ -45,15 +49,16 @@ __global__ __launch_bounds__(LR_THREADS, 2) void linear_regw_kernel(const LinPar
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
     unsigned char* tile = lds + wave * TILE_B;
+    const int mbase = blockIdx.y * M;
     const bf16_t* __restrict__ xg = (const bf16_t*)p.x;
-    bf16_t* __restrict__ yg = (bf16_t*)p.y;
+    bf16_t* __restrict__ yg = (bf16_t*)p.y + mbase;
 
     u32x4_t af[NH][KS];
 #pragma unroll
     for (int j = 0; j < NH; ++j)
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            const int m0 = j * 16;
+            const int m0 = mbase + j * 16;
             const int blk = m0 / p.cb, row = m0 - blk * p.cb + r;
             af[j][k] = ldg16((const unsigned char*)p.wp + ((((long long)blk * KS + k) * 4 + q) * p.cb + row) * 16);
         }
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(LR_THREADS, 2) void linear_regw_kernel(const LinPar
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
         bv[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv[j] = *(const f32x4_t*)(p.bias + j * 16 + q * 4);
+        if (p.bias) bv[j] = *(const f32x4_t*)(p.bias + mbase + j * 16 + q * 4);
     }
     bool kok[KS];                                       // this lane's chunk of k-step k lies inside the row
 #pragma unroll
@@ -99,33 +104,52 @@ __global__ __launch_bounds__(LR_THREADS, 2) void linear_regw_kernel(const LinPar
     }
 }
 
-template <int KS, int NH> int launch(const LinParams& p, hipStream_t stream) {
+template <int KS, int NH> int launch(const LinParams& p, int slices, hipStream_t stream) {
     const long long groups = (p.NV + 15) >> 4;
     long long gx = (groups + 3) / 4;
-    const long long cap = (long long)msseg_num_cus() * 2;
+    long long cap = (long long)msseg_num_cus() * 2 / slices;
+    if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL((linear_regw_kernel<KS, NH>), dim3((unsigned)gx), dim3(LR_THREADS), 0, stream, p);
+    hipLaunchKernelGGL((linear_regw_kernel<KS, NH>), dim3((unsigned)gx, (unsigned)slices), dim3(LR_THREADS), 0, stream, p);
     MSSEG_CHECK_LAUNCH("linear_regw");
     return MSSEG_OK;
 }
 
+constexpr int MAX_FRAGS = 24;   // weight fragments per lane (96 VGPRs)
+
+// output tiles per workgroup: the widest of {12, 9, 6, 4, 3, 2, 1} that divides the layer and fits the register budget
+int pick_nh(int ks, int Cout) {
+    static const int cand[] = {12, 9, 6, 4, 3, 2, 1};
+    for (int nh : cand)
+        if (Cout % (nh * 16) == 0 && ks * nh <= MAX_FRAGS) return nh;
+    return 0;
+}
+
+template <int KS> int launch_ks(const LinParams& p, int nh, int slices, hipStream_t stream) {
+    switch (nh) {
+        case 1: return launch<KS, 1>(p, slices, stream);
+        case 2: if constexpr (KS * 2 <= MAX_FRAGS) return launch<KS, 2>(p, slices, stream); break;
+        case 3: if constexpr (KS * 3 <= MAX_FRAGS) return launch<KS, 3>(p, slices, stream); break;
+        case 4: if constexpr (KS * 4 <= MAX_FRAGS) return launch<KS, 4>(p, slices, stream); break;
+        case 6: if constexpr (KS * 6 <= MAX_FRAGS) return launch<KS, 6>(p, slices, stream); break;
+        case 9: if constexpr (KS * 9 <= MAX_FRAGS) return launch<KS, 9>(p, slices, stream); break;
+        case 12: if constexpr (KS * 12 <= MAX_FRAGS) return launch<KS, 12>(p, slices, stream); break;
+    }
+    MSSEG_FAIL(MSSEG_EINVAL, "linear_regw: no instantiation for %d k-steps x %d output tiles", KS, nh);
+}
+
 }  // namespace
 
-// shapes with an instantiation: (k-steps, output tiles) of the first Swin stage at widths 48 / 144 / 192 and their
-// transposes; everything else stays on the generic kernel
-static bool lr_shape(int Cin, int Cout, int* ks, int* nh) {
-    if (Cout % 16 || Cin % 8) return false;
-    *ks = (Cin + 31) / 32;
-    *nh = Cout / 16;
-    const int k = *ks, n = *nh;
-    return (k == 2 && (n == 3 || n == 9 || n == 12)) || (n == 3 && (k == 5 || k == 6));
-}
+// k-step counts with an instantiation (input widths 33 ... 64, 65 ... 96, 129 ... 192, 257 ... 288, 353 ... 384, 545 ... 576,
+// 737 ... 768 and the 144-wide qkv gradient): the Swin stages at width 48 and its multiples; everything else stays generic
+static bool lr_ks_ok(int ks) { return ks == 2 || ks == 3 || ks == 5 || ks == 6 || ks == 9 || ks == 12 || ks == 18 || ks == 24; }
 
 bool msseg_linear_regw_eligible(int dtype, long long NV, int Cin, int Cout, const void* x, long long ldx, const void* y,
                                 long long ldy, const float* bias) {
     static const bool off = getenv("MSSEG_NO_LINEAR_REGW") != nullptr;   // A/B switch
-    int ks, nh;
-    if (off || dtype != MSSEG_BF16 || NV < 16384 || !lr_shape(Cin, Cout, &ks, &nh)) return false;
+    if (off || dtype != MSSEG_BF16 || NV < 1 || Cout % 16 || Cin % 8) return false;
+    const int ks = (Cin + 31) / 32;
+    if (!lr_ks_ok(ks) || pick_nh(ks, Cout) == 0) return false;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (ldx % 8) || (ldy % 8) || ldx < Cin || ldy < Cout) return false;
     if (bias && ((uintptr_t)bias & 15)) return false;
     return true;
@@ -136,11 +160,17 @@ int msseg_linear_regw_launch(const void* x, long long ldx, const void* wp, const
     LinParams p{};
     p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy; p.NV = NV; p.K = Cin;
     p.cb = msseg_cout_block(Cout);
-    int ks, nh;
-    if (!lr_shape(Cin, Cout, &ks, &nh)) MSSEG_FAIL(MSSEG_EINVAL, "linear_regw: shape %d -> %d has no instantiation", Cin, Cout);
-    if (ks == 2 && nh == 3) return launch<2, 3>(p, stream);
-    if (ks == 2 && nh == 9) return launch<2, 9>(p, stream);
-    if (ks == 2 && nh == 12) return launch<2, 12>(p, stream);
-    if (ks == 5 && nh == 3) return launch<5, 3>(p, stream);
-    return launch<6, 3>(p, stream);
+    const int ks = (Cin + 31) / 32, nh = pick_nh(ks, Cout);
+    if (!lr_ks_ok(ks) || nh == 0) MSSEG_FAIL(MSSEG_EINVAL, "linear_regw: shape %d -> %d has no instantiation", Cin, Cout);
+    const int slices = Cout / (nh * 16);
+    switch (ks) {
+        case 2: return launch_ks<2>(p, nh, slices, stream);
+        case 3: return launch_ks<3>(p, nh, slices, stream);
+        case 5: return launch_ks<5>(p, nh, slices, stream);
+        case 6: return launch_ks<6>(p, nh, slices, stream);
+        case 9: return launch_ks<9>(p, nh, slices, stream);
+        case 12: return launch_ks<12>(p, nh, slices, stream);
+        case 18: return launch_ks<18>(p, nh, slices, stream);
+        default: return launch_ks<24>(p, nh, slices, stream);
+    }
 }

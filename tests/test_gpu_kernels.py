@@ -631,8 +631,12 @@ def test_conv3d_k1_head(dtype, cin, cout):
     assert bool((buf[..., cout:] == 7.0).all())          # the padding channels are not touched
 
 
-@pytest.mark.parametrize("cin,cout", [(48, 144), (48, 48), (48, 192), (192, 48), (144, 48), (40, 48)])
-@pytest.mark.parametrize("tokens", [(2, 24, 24, 32), (1, 25, 27, 29)])
+@pytest.mark.parametrize("cin,cout,tokens", [
+    (48, 144, (2, 24, 24, 32)), (48, 48, (1, 25, 27, 29)), (48, 192, (1, 25, 27, 29)), (192, 48, (2, 24, 24, 32)),
+    (144, 48, (1, 25, 27, 29)), (40, 48, (1, 25, 27, 29)),
+    # deeper stages: output channels sliced over grid.y, few tokens (one 16-token group per wave or less)
+    (96, 288, (2, 12, 12, 13)), (384, 96, (2, 12, 12, 13)), (192, 576, (2, 6, 6, 7)), (768, 192, (2, 6, 6, 7)),
+    (384, 1152, (1, 3, 3, 5)), (576, 192, (2, 6, 6, 7)), (96, 96, (1, 1, 1, 7))])
 def test_linear_many_tokens_register_weight_kernel(cin, cout, tokens):
     """nn.Linear on >= 16 k tokens with the first Swin stage's widths (bf16): `linear_regw_kernel` (weights in registers,
     operand straight from global, LDS-transposed coalesced rows) for the forward and, through the transposed weight image,

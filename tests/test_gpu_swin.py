@@ -450,7 +450,8 @@ def test_segformer3d_vs_reference_golden(golden_dir, dtype):
         w = g["g:" + k]
         got = probe(P[k].grad).float().cpu().numpy()
         if np.linalg.norm(w) < 1e-3:      # a bias whose effect the training-mode BatchNorm removes: zero up to rounding noise
-            assert np.linalg.norm(got) < (1e-2 if dtype == torch.float32 else 1.0), k
+            # (bf16: a sum of ~10^4 rounded gradient values per channel; the realisation moves with any change of rounding order upstream)
+            assert np.linalg.norm(got) < (1e-2 if dtype == torch.float32 else 2.0), k
             continue
         eg[k] = float(np.linalg.norm(got - w) / np.linalg.norm(w))
     print(f"[{dtype}] SegFormer3D 64^3 forward errors:", {k: f"{v:.2e}" for k, v in ef.items()})
