@@ -98,11 +98,14 @@ MSSEG_DEVFN void finalize_channels(const float* ws, int N, int nblk, int C, int 
     const int G = 256 / cols;               // row groups
     const int col = threadIdx.x % cols, rg = threadIdx.x / cols;
     const bool in256 = threadIdx.x < 256;   // blocks may be larger than the 256 threads this routine tiles
-    for (int c0 = 0; c0 < L; c0 += cols) {
+    // blocks split the columns (and, where the samples stay separate -- mode 0 -- the samples over grid.y): with one block
+    // a 768-channel statistics row (L = 1536) took six sequential passes per sample
+    const int n_step = mode == 0 ? (int)gridDim.y : 1, n_first = mode == 0 ? (int)blockIdx.y : 0;
+    for (int c0 = blockIdx.x * cols; c0 < L; c0 += gridDim.x * cols) {
         const int o = c0 + col;
         const bool ok = in256 && o < L && rg < G;
         float tot = 0.f;
-        for (int n = 0; n < N; ++n) {
+        for (int n = n_first; n < N; n += n_step) {
             float s = 0.f;
             if (ok) {
                 const float* src = ws + (long long)n * nblk * L + o;
@@ -131,7 +134,8 @@ MSSEG_DEVFN void finalize_channels(const float* ws, int N, int nblk, int C, int 
     }
 }
 
-// Second step of every channel reduction: ONE 256-thread block adds the per-block partial rows (fixed order).  A
+// Second step of every channel reduction: 256-thread blocks (one per 256 columns, and per sample for statistics) add the
+// per-block partial rows in a fixed order.  A
 // separate launch -- the kernel boundary makes the rows visible, where an in-kernel "last block finalises" pays an
 // agent-scope release (L2 write-back) per block plus an acquire: ~10-15 us per reduction on these sizes.
 struct FinalizeArgs {
@@ -139,6 +143,14 @@ struct FinalizeArgs {
 };
 __global__ __launch_bounds__(256) void channels_finalize_kernel(const FinalizeArgs a) {
     finalize_channels(a.ws, a.N, a.nblk, a.C, a.nper, a.mode, a.out, a.dp0, a.dp1, a.accumulate);
+}
+
+static inline dim3 channels_finalize_grid(const FinalizeArgs& a) {
+    const int L = a.C * a.nper;
+    int gx = (L + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, a.mode == 0 ? (unsigned)(a.N < 1 ? 1 : a.N) : 1u);
 }
 
 // Reduction kernels run 512-thread blocks (8 waves per CU, one block per CU, 12+ loads in flight per thread): enough loads in flight to stream HBM
@@ -306,7 +318,7 @@ int launch_ln_param_grad(const void* x, long long ldx, const void* dy, long long
     MSSEG_CHECK_LAUNCH("ln_param_grad");
     {
         FinalizeArgs a{ws, 1, (int)blocks, C, 2, 2, ws + blocks * C * 2, dgamma, dbeta, accumulate};
-        hipLaunchKernelGGL(channels_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(channels_finalize_kernel, channels_finalize_grid(a), dim3(256), 0, st, a);
         MSSEG_CHECK_LAUNCH("channels_finalize");
     }
     return MSSEG_OK;
@@ -344,7 +356,7 @@ int launch_stats(const void* x, long long ldx, float* out, int N, long long S, i
     MSSEG_CHECK_LAUNCH("channel_stats");
     {
         FinalizeArgs a{ws, N, (int)blocks, C, nacc, nacc == 2 ? 0 : 1, out, nullptr, nullptr, accumulate};
-        hipLaunchKernelGGL(channels_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(channels_finalize_kernel, channels_finalize_grid(a), dim3(256), 0, st, a);
         MSSEG_CHECK_LAUNCH("channels_finalize");
     }
     return MSSEG_OK;
@@ -860,7 +872,7 @@ template <typename T, int MODE> int launch_norm(NormParams& p, int N, bool vec, 
     if (MODE == 1) {
         // red[n][c] = (sum dz, sum dz*xhat); dbeta = sum_n red0, dgamma = sum_n red1
         FinalizeArgs a{p.ws, N, (int)blocks, p.C, 2, 2, p.red, p.dbeta, p.dgamma, p.accumulate};
-        hipLaunchKernelGGL(channels_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(channels_finalize_kernel, channels_finalize_grid(a), dim3(256), 0, st, a);
         MSSEG_CHECK_LAUNCH("channels_finalize");
     }
     return MSSEG_OK;
@@ -1474,7 +1486,7 @@ int msseg_instnorm_act_poolbwd_reduce(const void* x, long long ldx, const float*
                hipLaunchKernelGGL(instnorm_poolbwd_reduce_kernel<bf16_t>, grid, dim3(RED_THREADS), 0, (hipStream_t)stream, p));
     MSSEG_CHECK_LAUNCH("instnorm_act_poolbwd_reduce");
     FinalizeArgs a{p.ws, N, (int)blocks, C, 2, 2, red, dbeta, dgamma, accumulate};
-    hipLaunchKernelGGL(channels_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(channels_finalize_kernel, channels_finalize_grid(a), dim3(256), 0, (hipStream_t)stream, a);
     MSSEG_CHECK_LAUNCH("channels_finalize");
     return MSSEG_OK;
 }
