@@ -1019,6 +1019,24 @@ __global__ void add_kernel(const T* a, long long lda, const T* b, long long ldb,
     }
 }
 
+// the same on 16-byte chunks (rows of C channels inside wider buffers: ld >= C, everything a multiple of a chunk)
+template <typename T>
+__global__ __launch_bounds__(256) void add_vec_kernel(const T* __restrict__ a, long long lda, const T* __restrict__ b,
+                                                      long long ldb, T* __restrict__ y, long long ldy, long long rows, int cpr) {
+    constexpr int EPC = DT<T>::EPC;
+    const long long total = rows * cpr;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cpr;
+        const int c = (int)(i - r * cpr) * EPC;
+        Chunk<T> ca, cb, o;
+        ca.load(a + r * lda + c);
+        cb.load(b + r * ldb + c);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.v[e] = ca.v[e] + cb.v[e];
+        o.store(y + r * ldy + c);
+    }
+}
+
 // y[n][r][:] = a[n][r][:] + s[n] * b[n][r][:]   (a nullable: y = s * b; s nullable: s = 1) -- the residual add of the Swin
 // blocks with the per-sample stochastic-depth scale mask[n] / keep folded in (models/layers/drop_path.py:15-45), and its
 // backward (branch gradient = s[n] * dy).  16-byte chunks, rows_per_sample rows per sample.
@@ -1612,6 +1630,21 @@ int msseg_zero_stuff2(const void* dy, long long lddy, void* out, long long ldo, 
 int msseg_add(const void* a, long long lda, const void* b, long long ldb, void* y, long long ldy, long long rows, int C,
               int dtype, msseg_stream_t stream) {
     if (!a || !b || !y || rows < 1 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "add: bad args");
+    {
+        const int esz = dtype == MSSEG_F32 ? 4 : 2, epc = 16 / esz;
+        if (C % epc == 0 && lda % epc == 0 && ldb % epc == 0 && ldy % epc == 0 &&
+            ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0) {
+            const int cpr = C / epc;
+            const int gv = grid_for(rows * cpr, 2);
+            DISPATCH_T(dtype,
+                       hipLaunchKernelGGL(add_vec_kernel<float>, dim3(gv), dim3(256), 0, (hipStream_t)stream, (const float*)a,
+                                          lda, (const float*)b, ldb, (float*)y, ldy, rows, cpr),
+                       hipLaunchKernelGGL(add_vec_kernel<bf16_t>, dim3(gv), dim3(256), 0, (hipStream_t)stream,
+                                          (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)y, ldy, rows, cpr));
+            MSSEG_CHECK_LAUNCH("add");
+            return MSSEG_OK;
+        }
+    }
     const int g = grid_for(rows * C);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(add_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)a, lda,
