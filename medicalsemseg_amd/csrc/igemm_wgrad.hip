@@ -512,6 +512,10 @@ int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes
     const int wave_slots = 1;   // one slab per workgroup (the flat kernels add their four waves through LDS)
     const size_t slab_bytes = (size_t)C::SLAB_FLOATS * 4;
     long long gx = msseg_num_cus() * ((C::LDS_BYTES > 80 * 1024) ? 1 : 2);
+    // flat (1-tap) problems: a tile is 8 MFMAs per wave behind a load -> LDS -> barrier round trip and a slab is 4 KB, so
+    // resident workgroups are what hides the latency: as many as the 48 KB of LDS per workgroup allow (MSSEG_WG_FLAT_PER_CU)
+    static const int flat_per_cu = getenv("MSSEG_WG_FLAT_PER_CU") ? atoi(getenv("MSSEG_WG_FLAT_PER_CU")) : 3;
+    if (NTAPS == 1 && C::LDS_BYTES * flat_per_cu <= 160 * 1024) gx = (long long)msseg_num_cus() * flat_per_cu;
     // Small grids (the 24^3 ... 6^3 levels): every workgroup writes a 110 KB slab whatever it computed, so a full chip
     // of workgroups moves 56 MB of slabs (written, then read by the reduction) for a few GFLOP.  Half a workgroup per CU
     // measured fastest there (sweep 64 ... 512 in profiles/README.md): 30-34 -> 21-25 us per layer.
