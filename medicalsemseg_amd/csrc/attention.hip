@@ -361,15 +361,25 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const LnVecParams p)
             }
         }
         if constexpr (!BWD) {
-            float s = 0.f, s2 = 0.f;
+            // the row is in registers: mean first, then the centred sum of squares (E[x^2] - mean^2 loses
+            // eps * mean^2 / var, which shows on wide rows with a large mean)
+            float s = 0.f;
 #pragma unroll
             for (int k = 0; k < MAXCH; ++k)
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) { s += xv[k][e]; s2 += xv[k][e] * xv[k][e]; }
-            for (int o = p.lpr >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o); }
+                for (int e = 0; e < EPC; ++e) s += xv[k][e];
+            for (int o = p.lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
             const float mu = s * invC;
-            float var = s2 * invC - mu * mu;
-            var = var > 0.f ? var : 0.f;
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXCH; ++k) {
+                if (sub + k * p.lpr < p.nch) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) { const float d = xv[k][e] - mu; s2 += d * d; }
+                }
+            }
+            for (int o = p.lpr >> 1; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+            const float var = s2 * invC;
             const float rs = rsqrtf(var + p.eps);
             if (rok && sub == 0 && p.mean) { p.mean[r] = mu; p.rstd[r] = rs; }
 #pragma unroll
@@ -420,7 +430,9 @@ template <typename T, bool BWD> bool launch_ln_vec(LnVecParams p, hipStream_t st
     while (lpr < p.nch && lpr < 64) lpr <<= 1;
     p.lpr = lpr;
     const int maxch = (p.nch + lpr - 1) / lpr;
-    if (maxch > 4) return false;
+    // (rows wider than 8 x 64 chunks -- 4096 bf16 channels -- fall back to the scalar kernel: one thread per row.  The 3072-wide
+    //  LayerNorm of the MONAI variant's last patch merging ran there at 1 ms per pass for 54 rows.)
+    if (maxch > 8) return false;
     const long long waves = (p.rows + (64 / lpr) - 1) / (64 / lpr);
     long long blocks = (waves + 3) / 4;
     const long long cap = (long long)msseg_num_cus() * 8;
@@ -431,7 +443,9 @@ template <typename T, bool BWD> bool launch_ln_vec(LnVecParams p, hipStream_t st
         case 1: hipLaunchKernelGGL((layernorm_vec_kernel<T, 1, BWD>), grid, dim3(256), 0, stream, p); break;
         case 2: hipLaunchKernelGGL((layernorm_vec_kernel<T, 2, BWD>), grid, dim3(256), 0, stream, p); break;
         case 3: hipLaunchKernelGGL((layernorm_vec_kernel<T, 3, BWD>), grid, dim3(256), 0, stream, p); break;
-        default: hipLaunchKernelGGL((layernorm_vec_kernel<T, 4, BWD>), grid, dim3(256), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((layernorm_vec_kernel<T, 4, BWD>), grid, dim3(256), 0, stream, p); break;
+        case 5: case 6: hipLaunchKernelGGL((layernorm_vec_kernel<T, 6, BWD>), grid, dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL((layernorm_vec_kernel<T, 8, BWD>), grid, dim3(256), 0, stream, p); break;
     }
     return true;
 }

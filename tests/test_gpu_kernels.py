@@ -631,6 +631,34 @@ def test_conv3d_k1_head(dtype, cin, cout):
     assert bool((buf[..., cout:] == 7.0).all())          # the padding channels are not touched
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C,affine", [((2, 3, 3, 3), 3072, True), ((2, 3, 3, 3), 1536, True), ((1, 5, 6, 7), 384, True),
+                                            ((2, 6, 7, 8), 48, False), ((1, 4, 5, 6), 40, True), ((1, 2, 2, 3), 4104, True)])
+def test_layer_norm_wide_and_narrow_rows(dtype, rows, C, affine):
+    """ops.layer_norm forward / backward vs torch on the rounded operands: the vector kernel up to 8 chunks per lane (the
+    3072-wide LayerNorm of the MONAI variant's last patch merging: /root/reference/models/segmentors/swin_unetr_official.py:699-708),
+    un-affine (proj_out, :955-968), and the scalar fall-backs (40 channels: no 16-byte chunks in bf16; 4104: beyond 8 x 64 chunks)"""
+    from medicalsemseg_amd import ops
+    dev = _dev()
+    x = gen(*rows, C, seed=61)
+    g, b = gen(C, seed=62) * 0.3 + 1.0, gen(C, seed=63) * 0.3
+    dy = gen(*rows, C, seed=64)
+    xr, dyr = rnd(dtype, x, dy)
+    xr.requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yref = F.layer_norm(xr, (C,), gr if affine else None, br if affine else None, 1e-5)
+    yref.backward(dyr)
+    xg = x.detach().clone().to(dev, dtype).requires_grad_(True)     # (rnd() aliases x in fp32)
+    gp, bp = torch.nn.Parameter(g.to(dev)), torch.nn.Parameter(b.to(dev))
+    y = ops.layer_norm(xg, gp if affine else None, bp if affine else None, 1e-5)
+    y.backward(dy.to(dev, dtype))
+    check(y.detach(), yref.detach(), dtype, "layer_norm fwd")
+    check(xg.grad, xr.grad, dtype, "layer_norm dx")
+    if affine:
+        check(gp.grad, gr.grad, dtype, "layer_norm dgamma")
+        check(bp.grad, br.grad, dtype, "layer_norm dbeta")
+
+
 @pytest.mark.parametrize("cin,cout,tokens", [
     (48, 144, (2, 24, 24, 32)), (48, 48, (1, 25, 27, 29)), (48, 192, (1, 25, 27, 29)), (192, 48, (2, 24, 24, 32)),
     (144, 48, (1, 25, 27, 29)), (40, 48, (1, 25, 27, 29)),
