@@ -65,22 +65,40 @@ WORK = {
                        "name": "UNet base 1->{c}cls, {v}^3 volume, roi {s}^3, overlap 0.5, gaussian, {w} windows, sw_batch {b}"},
 }
 
+# timer group (an entry point of the C ABI, split by the kernel variant its planner picks) -> (description, the main
+# kernel's name in the library's own event pairs: msseg_ktimer_*)
 KERNEL_NAMES = {
-    "conv3d_k3_fwd/v3": "k3pp_kernel (conv3d k3 fwd + dgrad, bf16, 32-input-channel stages, 4x4x16 tiles, LDS-DMA ping-pong)",
-    "conv3d_k3_fwd/v0": "igemm_fwd_kernel<27,DIRECT,STORE,4,8,16,8> (conv3d k3 fwd + dgrad, 4x8x16 tiles)",
-    "conv3d_k3_fwd/v1": "igemm_fwd_kernel<27,DIRECT,STORE,4,4,8,4> (conv3d k3 fwd + dgrad, 4x4x8 tiles)",
-    "conv3d_k3_fwd/v2": "igemm_fwd_kernel<27,DIRECT,STORE,2,4,8,4> (conv3d k3 fwd + dgrad, 2x4x8 tiles)",
-    "conv3d_k3_wgrad": "k3wg_pp_kernel / igemm_wgrad_kernel (conv3d k3 weight gradient)",
+    "conv3d_k3_fwd/v3": ("k3pp_kernel (conv3d k3 fwd + dgrad, bf16, 32-input-channel stages, 4x4x16 tiles, LDS-DMA ping-pong)",
+                         ("k3pp_kernel",)),
+    "conv3d_k3_fwd/v0": ("igemm_fwd_kernel<27,DIRECT,STORE,4,8,16,8> (conv3d k3 fwd + dgrad, 4x8x16 tiles)", ("igemm_fwd_kernel<27,4x8x16>",)),
+    "conv3d_k3_fwd/v1": ("igemm_fwd_kernel<27,DIRECT,STORE,4,4,8,4> (conv3d k3 fwd + dgrad, 4x4x8 tiles)", ("igemm_fwd_kernel<27,4x4x8>",)),
+    "conv3d_k3_fwd/v2": ("igemm_fwd_kernel<27,DIRECT,STORE,2,4,8,4> (conv3d k3 fwd + dgrad, 2x4x8 tiles)", ("igemm_fwd_kernel<27,2x4x8>",)),
+    "conv3d_k3_wgrad/v3": ("k3wg_pp_kernel (conv3d k3 weight gradient, 32-channel block pairs, ping-pong)", ("k3wg_pp_kernel",)),
+    "conv3d_k3_wgrad/v0": ("igemm_wgrad_kernel<27> (conv3d k3 weight gradient, generic)", ("igemm_wgrad_kernel<27>",)),
 }
+MFMA_BOUND_FLOP_PER_BYTE = 60.0   # groups above this algorithmic intensity are priced against the MFMA peak, the rest against HBM
 
 
 def host_cores():
-    cores = os.cpu_count() or 1
+    """(threads the CPU leg uses, cores this process may run on).  The GPU box grants one GPU's CPU share (16 cores); more
+    torch threads than that oversubscribe the share and slow the oracle down, so the leg uses at most 16 and says so."""
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    return min(cores, 16)   # the GPU box grants one GPU's CPU share (16 cores); oversubscribing slows torch down
+    return min(avail, 16), avail
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def synth_batch(batch, size, n_cls, device, seed):
@@ -96,10 +114,10 @@ def synth_batch(batch, size, n_cls, device, seed):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline_train(workload, batch, size, n_cls, budget_s=25.0):
+def cpu_baseline_train(workload, batch, size, n_cls, budget_s=40.0):
     """The CPU oracle (torch fp32, host cores) on the same synthetic training step; bounded sample."""
     from oracle.losses import dice_ce_loss
-    cores = host_cores()
+    cores, avail = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     if workload == "unet":
@@ -132,7 +150,8 @@ def cpu_baseline_train(workload, batch, size, n_cls, budget_s=25.0):
     times = []
     t_all = time.perf_counter()
     flops = None
-    for i in range(4):
+    WARM, TIMED = 2, 5            # median of >= 5 steps after 2 warm-ups
+    for i in range(WARM + TIMED):
         t0 = time.perf_counter()
         if i == 0 and WORK[workload]["gflop_per_vol"] is None:
             from torch.utils.flop_counter import FlopCounterMode
@@ -146,14 +165,16 @@ def cpu_baseline_train(workload, batch, size, n_cls, budget_s=25.0):
         opt.step()
         opt.zero_grad()
         times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > budget_s and i >= 1:
+        if time.perf_counter() - t_all > budget_s and i >= WARM:   # slow models: keep the leg bounded, say what was timed
             break
-    steady = times[1:] if len(times) > 1 else times
+    nwarm = min(WARM, len(times) - 1)
+    steady = times[nwarm:]
     med = sorted(steady)[len(steady) // 2]
     extra = {} if flops is None else {"counted_gflop_per_vol": round(flops / batch / 1e9, 1)}
-    return {**extra, "value": round(batch / med, 4), "unit": "vol/s", "cores": cores, "kind": "port",
-            "sample": f"{len(steady)} timed step(s) (after 1 warm-up) of the same B={batch} {size}^3 fwd+DiceCE+bwd+AdamW "
-                      f"step, {what} fp32 on torch-CPU, median {med:.2f} s/step"}
+    return {**extra, "value": round(batch / med, 4), "unit": "vol/s", "cores": cores, "cores_available": avail,
+            "cpu_model": cpu_model(), "kind": "port",
+            "sample": f"median of {len(steady)} timed step(s) after {nwarm} warm-up(s) of the same B={batch} {size}^3 "
+                      f"fwd+DiceCE+bwd+AdamW step, {what} fp32 on torch-CPU with {cores} threads, {med:.2f} s/step"}
 
 
 def cpu_baseline_sw(size, n_cls, n_windows, sw_batch=4, budget_s=25.0):
@@ -161,7 +182,7 @@ def cpu_baseline_sw(size, n_cls, n_windows, sw_batch=4, budget_s=25.0):
     to the job's window count."""
     from oracle.blocks import BasicUNet
     from oracle.sliding_window import compute_importance_map
-    cores = host_cores()
+    cores, avail = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     net = BasicUNet(1, n_cls).eval()
@@ -171,7 +192,8 @@ def cpu_baseline_sw(size, n_cls, n_windows, sw_batch=4, budget_s=25.0):
     cnt = torch.zeros(n_cls, size, size, size)
     done, t_all = 0, time.perf_counter()
     with torch.no_grad():
-        net(torch.randn(1, 1, size, size, size, generator=g))       # warm-up
+        for _ in range(2):
+            net(torch.randn(1, 1, size, size, size, generator=g))   # warm-ups
         t0 = time.perf_counter()
         while done < 20 or (time.perf_counter() - t_all < budget_s and done < 40):
             seg = net(torch.randn(sw_batch, 1, size, size, size, generator=g))
@@ -181,19 +203,49 @@ def cpu_baseline_sw(size, n_cls, n_windows, sw_batch=4, budget_s=25.0):
             done += sw_batch
         dt = time.perf_counter() - t0
     per_win = dt / done
-    return {"value": round(1.0 / (per_win * n_windows), 6), "unit": "vol/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / (per_win * n_windows), 6), "unit": "vol/s", "cores": cores, "cores_available": avail,
+            "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{done} windows of {size}^3 (forward of oracle/ BasicUNet fp32 on torch-CPU in batches of {sw_batch} + "
                       f"weighted blend), {per_win:.3f} s/window, extrapolated to the {n_windows} windows of one volume"}
 
 
-def roofline_from_timer(summ, dtype, step_ms, instr_steps, prefer=None):
-    """dominant instrumented kernel (largest total time) -> the roofline object"""
+def roofline_from_timer(summ, ksumm, dtype, step_ms, instr_steps):
+    """The roofline object of the step's DOMINANT group -- the timer group with the largest measured total time (every
+    entry point of the library is bracketed by HIP events on the launch stream while the timer is on) -- plus the top
+    five groups.  `achieved` of the dominant group = its algorithmic flops (or bytes) / the duration of its MAIN kernel
+    alone (the library's own event pairs around that launch, `ksumm`); where the library records no pair for the group the
+    entry point's duration is used, which includes its small follow-up kernels."""
     if not summ:
         return None
-    kid = prefer if prefer in summ else max(summ, key=lambda k: summ[k]["total_ms"])
-    k = summ[kid]
-    tf = k["flops"] / (k["total_ms"] * 1e-3) / 1e12
-    peak = MFMA_PEAK_BF16_TFLOPS if dtype == "bf16" else MFMA_PEAK_F32_TFLOPS
+    mfma_peak = MFMA_PEAK_BF16_TFLOPS if dtype == "bf16" else MFMA_PEAK_F32_TFLOPS
+    esz_scale = 1.0
+    total = sum(v["total_ms"] for v in summ.values())
+
+    def price(kid, v):
+        desc, knames = KERNEL_NAMES.get(kid, (kid, ()))
+        ms = v["total_ms"]
+        kern_ms = sum(ksumm[n]["total_ms"] for n in knames if n in ksumm) if ksumm else 0.0
+        kern_n = sum(ksumm[n]["launches"] for n in knames if n in ksumm) if ksumm else 0
+        own = kern_ms if (kern_ms > 0 and kern_n == v["launches"]) else None   # the main kernel alone, else the entry point
+        t = (own if own is not None else ms) * 1e-3
+        g = {"name": desc, "group": kid, "launches_per_step": round(v["launches"] / instr_steps, 1),
+             "share_of_step": round((ms / instr_steps) / step_ms, 3), "avg_ms": round(ms / v["launches"], 4),
+             "kernel_avg_ms": round(own / v["launches"], 4) if own is not None else None}
+        fl, by = v["flops"], v["bytes"]
+        if fl > 0 and (by <= 0 or fl / by >= MFMA_BOUND_FLOP_PER_BYTE):
+            tf = fl / t / 1e12
+            g.update(bound="mfma", achieved=round(tf, 2), unit="TFLOP/s", frac=round(tf / mfma_peak, 4))
+        elif by > 0:
+            gbs = by * esz_scale / t / 1e9
+            g.update(bound="hbm", achieved=round(gbs, 1), unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4))
+        else:
+            g.update(bound=None, achieved=None, unit=None, frac=None)
+        return g
+
+    order = sorted(summ, key=lambda k: -summ[k]["total_ms"])
+    groups = [price(k, summ[k]) for k in order[:5]]
+    kid = order[0]
+    k, top = summ[kid], groups[0]
     traffic = tshape = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE x2 + WRITE_SIZE
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
@@ -202,27 +254,26 @@ def roofline_from_timer(summ, dtype, step_ms, instr_steps, prefer=None):
             traffic, tshape = ent["hbm_bytes_per_launch"], ent.get("shape")
     except (OSError, ValueError):
         pass
-    allk = [v for kk, v in summ.items() if kk.startswith("conv3d_k3_fwd")]
-    r = {"bound": "mfma", "kernel": KERNEL_NAMES.get(kid, kid), "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-         "frac": round(tf / peak, 4), "traffic": traffic, "traffic_shape": tshape, "launches": k["launches"],
-         "avg_ms": round(k["avg_ms"], 4), "flops_per_launch_avg": round(k["flops"] / k["launches"]),
+    r = {"bound": top["bound"] or "hbm", "kernel": top["name"], "selected_by": "largest measured total time over the timer groups",
+         "achieved": top["achieved"], "peak": mfma_peak if top["bound"] == "mfma" else HBM_PEAK_GBS, "unit": top["unit"],
+         "frac": top["frac"], "traffic": traffic, "traffic_shape": tshape, "launches": k["launches"],
+         "avg_ms": top["kernel_avg_ms"] if top["kernel_avg_ms"] is not None else top["avg_ms"],
+         "avg_ms_measures": "the main kernel alone (library event pair around its launch)" if top["kernel_avg_ms"] is not None
+                            else "the entry point (its follow-up kernels included)",
+         "flops_per_launch_avg": round(k["flops"] / k["launches"]),
          "algorithmic_bytes_per_launch_avg": round(k["bytes"] / k["launches"]),
-         "share_of_step": round((k["total_ms"] / instr_steps) / step_ms, 3)}
-    if allk:
-        r["all_k3_variants_tflops"] = round(sum(v["flops"] for v in allk) / (sum(v["total_ms"] for v in allk) * 1e-3) / 1e12, 2)
-    w = summ.get("conv3d_k3_wgrad")
-    if w and kid != "conv3d_k3_wgrad":
-        r["wgrad_tflops"] = round(w["flops"] / (w["total_ms"] * 1e-3) / 1e12, 2)
-        r["wgrad_share_of_step"] = round((w["total_ms"] / instr_steps) / step_ms, 3)
+         "share_of_step": top["share_of_step"], "instrumented_share_of_step": round((total / instr_steps) / step_ms, 3),
+         "groups": groups}
     return r
 
 
-def bench_sliding_window(args, dev, dtype, world, rank):
-    """512^3 sliding-window inference (roi 96^3, overlap 0.5, gaussian; 1000 windows) with the UNet in eval mode.
-    N > 1: window batches dealt round-robin to the ranks, one all-gather of logits per step, every rank blends."""
+def measure_sliding_window(args, dev, dtype, world, rank, steps, warmup, with_roofline=True):
+    """512^3 sliding-window inference (roi 96^3, overlap 0.5, gaussian; 1000 windows) with the UNet in eval mode: the second
+    half of BASELINE.json's metric.  N > 1: window batches dealt round-robin to the ranks, one all-gather of logits per
+    step, every rank blends.  Returns the result dict on rank 0 (None elsewhere)."""
     from medicalsemseg_amd import hip
     from medicalsemseg_amd.engine import utils as U
-    from medicalsemseg_amd.models.unet import LOGIT_LD, UNet
+    from medicalsemseg_amd.models.unet import UNet
     net = UNet(1, args.classes, compute_dtype=dtype).to(dev).eval()
     g = torch.Generator().manual_seed(13)            # the same volume on every rank (shard_ranks contract)
     vol = torch.randn(1, 1, args.sw_size, args.sw_size, args.sw_size, generator=g).to(dev)
@@ -240,11 +291,11 @@ def bench_sliding_window(args, dev, dtype, world, rank):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         out = run()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = run()
     sync()
     dt = time.perf_counter() - t0
@@ -252,42 +303,92 @@ def bench_sliding_window(args, dev, dtype, world, rank):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    if rank == 0:
-        value = args.steps / dt
-        w = WORK["sliding_window"]
-        nsteps = -(-n_win // (args.sw_batch * world))
-        res = {"metric": w["metric"] if args.sw_size == 512 else f"{args.sw_size}^3 sliding-window vols/sec",
-               "value": round(value, 4), "unit": "vol/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "launch": "hipGraph replay of the window forward",
-               "config": {"workload": w["name"].format(c=args.classes, v=args.sw_size, s=args.size, w=n_win, b=args.sw_batch),
-                          "parallelism": f"window batches round-robin over {world} rank(s)" + (
-                              ", one all-gather of compact logits per step, under the next step's forward" if world > 1 else ""),
-                          "windows_per_rank": [sum(1 for s in range(nsteps) for j in range(args.sw_batch)
-                                                   if (s * world + r) * args.sw_batch + j < n_win) for r in range(world)],
-                          "all_gather_bytes_per_rank_per_volume": (0 if world == 1 else
-                              nsteps * world * args.sw_batch * args.size ** 3 * args.classes * (2 if args.dtype == "bf16" else 4)),
-                          "out_mean": round(float(out.mean()), 5)}}
-        scale = (args.sw_size / 512.0) ** 3
-        res["model_tflops"] = round(value * w["gflop_per_vol"] * n_win / 1000.0 / 1e3, 2)
-        res["hbm_roofline_frac_algorithmic"] = round(value * w["gb_per_vol_bf16"] * scale / HBM_PEAK_GBS, 4)
-        # dominant kernel: instrumented eager window batches right after the timed region
+    if rank != 0:
+        return None
+    value = steps / dt
+    w = WORK["sliding_window"]
+    nsteps = -(-n_win // (args.sw_batch * world))
+    res = {"metric": w["metric"] if args.sw_size == 512 else f"{args.sw_size}^3 sliding-window vols/sec",
+           "value": round(value, 4), "unit": "vol/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "launch": "hipGraph replay of the window forward",
+           "config": {"workload": w["name"].format(c=args.classes, v=args.sw_size, s=args.size, w=n_win, b=args.sw_batch),
+                      "parallelism": f"window batches round-robin over {world} rank(s)" + (
+                          ", one all-gather of compact logits per step, under the next step's forward" if world > 1 else ""),
+                      "windows_per_rank": [sum(1 for s in range(nsteps) for j in range(args.sw_batch)
+                                               if (s * world + r) * args.sw_batch + j < n_win) for r in range(world)],
+                      "all_gather_bytes_per_rank_per_volume": (0 if world == 1 else
+                          nsteps * world * args.sw_batch * args.size ** 3 * args.classes * (2 if args.dtype == "bf16" else 4)),
+                      "out_mean": round(float(out.mean()), 5)}}
+    scale = (args.sw_size / 512.0) ** 3
+    res["model_tflops"] = round(value * w["gflop_per_vol"] * n_win / 1000.0 / 1e3, 2)
+    res["hbm_roofline_frac_algorithmic"] = round(value * w["gb_per_vol_bf16"] * scale / HBM_PEAK_GBS, 4)
+    if with_roofline:
+        # dominant group: instrumented eager window batches right after the timed region
         win = torch.zeros(args.sw_batch, args.size, args.size, args.size, 1, dtype=dtype, device=dev)
         hip.TIMER.records.clear()
+        hip.ktimer_summary()
         hip.TIMER.enabled = True
+        hip.ktimer_enable(True)
         nrep = 3
         for _ in range(nrep):
             net.infer_cl(win)
         torch.cuda.synchronize()
         hip.TIMER.enabled = False
-        batch_ms = dt / args.steps * 1e3 / nsteps
-        res["roofline"] = roofline_from_timer(hip.TIMER.summary(), args.dtype, batch_ms, nrep, "conv3d_k3_fwd/v3")
+        hip.ktimer_enable(False)
+        batch_ms = dt / steps * 1e3 / nsteps
+        res["roofline"] = roofline_from_timer(hip.TIMER.summary(), hip.ktimer_summary(), args.dtype, batch_ms, nrep)
+    return res, n_win
+
+
+def bench_sliding_window(args, dev, dtype, world, rank):
+    r = measure_sliding_window(args, dev, dtype, world, rank, args.steps, args.warmup)
+    if rank == 0:
+        res, n_win = r
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_sw(args.size, args.classes, n_win)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def dist_facts(dev, world, rank, nbytes):
+    """what the collective library saw: makes the first multi-GPU run self-validating"""
+    import torch.distributed as dist
+    facts = {"world_size": world}
+    if world == 1:
+        return facts
+    facts["backend"] = dist.get_backend()
+    try:
+        v = torch.cuda.nccl.version()
+        facts["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:  # noqa: BLE001
+        facts["rccl_version"] = f"unavailable ({type(e).__name__})"
+    idx = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=dev)
+    allidx = [torch.zeros_like(idx) for _ in range(world)]
+    dist.all_gather(allidx, idx)
+    facts["device_index_per_rank"] = [int(t.item()) for t in allidx]
+    name = torch.cuda.get_device_name(dev)
+    facts["device_name_rank0"] = name
+    # one all-reduce of a gradient-sized fp32 buffer, event-timed outside the graphs (5 after 2 warm-ups, max over ranks)
+    buf = torch.zeros(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dist.barrier()
+    e0.record()
+    for _ in range(5):
+        dist.all_reduce(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    t = torch.tensor([e0.elapsed_time(e1) / 5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    facts["grad_allreduce_ms"] = round(float(t.item()), 4)
+    facts["grad_allreduce_bytes"] = int(buf.numel() * 4)
+    facts["grad_allreduce_busbw_GBs"] = round(2 * (world - 1) / world * buf.numel() * 4 / (float(t.item()) * 1e-3) / 1e9, 1)
+    return facts
 
 
 def main():
@@ -307,6 +408,9 @@ def main():
                                                          "swinception"],
                     help="unet = the headline (BASELINE configs[1]); swin_unetr = configs[3]; sliding_window = configs[4]; "
                          "segformer3d / swin_depth / swinception = the SURVEY 8(f) N3 / N4 model families")
+    ap.add_argument("--no-sliding-window", action="store_true",
+                    help="default workload only: skip the 512^3 sliding-window leg (the second half of BASELINE.json's metric)")
+    ap.add_argument("--sw-steps", type=int, default=3, help="timed 512^3 volumes of the sliding-window leg of the default line")
     ap.add_argument("--sw-size", type=int, default=512)
     ap.add_argument("--sw-batch", type=int, default=8)   # windows per forward
     args = ap.parse_args()
@@ -469,25 +573,37 @@ def main():
         loss = static_loss
     else:
         hip.TIMER.enabled = True
+        hip.ktimer_enable(True)
         for _ in range(args.steps):
             loss = step()
     sync()
+    hip.ktimer_enable(False)
     dt = time.perf_counter() - t0
     hip.TIMER.enabled = False
     instr_steps = args.steps
     if graph is not None:
         instr_steps = min(args.steps, 5)
         # per-kernel HIP-event timing needs eager launches: instrument a few extra steps right after the timed region
+        hip.TIMER.records.clear()
+        hip.ktimer_summary()
         hip.TIMER.enabled = True
+        hip.ktimer_enable(True)
         for _ in range(instr_steps):
             step()
         sync()
         hip.TIMER.enabled = False
+        hip.ktimer_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss_v = float(loss.detach())
+    facts = dist_facts(dev, world, rank, opt.flat_grad.numel() * 4)
+    # The other half of BASELINE.json's metric ("... & 512^3 sliding-window vols/sec"): part of the default line so that
+    # the driver's run times both halves.  All ranks take part (window batches are sharded over them).
+    sw_res = None
+    if args.workload == "unet" and not args.no_sliding_window:
+        sw_res = measure_sliding_window(args, dev, dtype, world, rank, args.sw_steps, 1, with_roofline=False)
 
     vols = args.batch * args.steps * world
     value = vols / dt
@@ -501,7 +617,7 @@ def main():
                    else "hipGraph replay (fwd+bwd | all-reduce | optimiser)")
                   if graph is not None else "eager",
         "config": {"workload": w["name"].format(c=args.classes, s=args.size, b=args.batch), "global_batch": args.batch * world,
-                   "parallelism": f"dp{world}", "final_loss": round(loss_v, 5),
+                   "parallelism": f"dp{world}", "final_loss": round(loss_v, 5), "distributed": facts,
                    "grad_sync": ("none (single rank)" if world == 1 else
                                  f"flat fp32 gradient buffer, {opt.flat_grad.numel() * 4} bytes per step, " +
                                  ("two all-reduces, the first under the backward tail" if gsync.overlapped else "one all-reduce"))},
@@ -509,12 +625,17 @@ def main():
     if rank == 0:
         scale = (args.size / 96.0) ** 3
         step_ms = dt * 1e3 / args.steps
-        res["roofline"] = roofline_from_timer(hip.TIMER.summary(), args.dtype, step_ms, instr_steps,
-                                              "conv3d_k3_fwd/v3" if args.workload == "unet" else None)
+        res["roofline"] = roofline_from_timer(hip.TIMER.summary(), hip.ktimer_summary(), args.dtype, step_ms, instr_steps)
         if w["gflop_per_vol"] is not None:
             res["model_tflops"] = round(value / world * w["gflop_per_vol"] * scale / 1e3, 2)
             res["hbm_roofline_frac_algorithmic"] = round(value / world * w["gb_per_vol_bf16"] * scale *
                                                          (1 if args.dtype == "bf16" else 2) / HBM_PEAK_GBS, 4)
+        if sw_res is not None:
+            r, n_win = sw_res
+            res["sliding_window"] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"],
+                                     "warmup": r["warmup"], "ms_per_step": r["ms_per_step"], "scaling": r["scaling"],
+                                     "model_tflops": r["model_tflops"], "launch": r["launch"],
+                                     "hbm_roofline_frac_algorithmic": r["hbm_roofline_frac_algorithmic"], "config": r["config"]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_train(args.workload, args.batch, args.size, args.classes)
             if "counted_gflop_per_vol" in res["cpu_baseline"]:

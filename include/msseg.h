@@ -43,6 +43,15 @@ const char* msseg_last_error(void);
 /* number of compute units of the current device (grid sizing of the persistent kernels) */
 int msseg_num_cus(void);
 
+/* Measurement aid (no reference counterpart): while enabled, the launches of the main convolution kernels (k3pp_kernel,
+ * k3wg_pp_kernel, igemm_fwd_kernel, igemm_wgrad_kernel) are bracketed by a hipEvent pair on their stream; `_get` returns
+ * the kernel's name and the elapsed time of record i (it waits for that launch).  Process-wide, not for use while a
+ * stream is capturing.  bench.py derives `roofline.achieved` of the dominant kernel from these. */
+int msseg_ktimer_enable(int on);
+int msseg_ktimer_reset(void);
+int msseg_ktimer_count(void);
+int msseg_ktimer_get(int i, char* name, int cap, float* ms);
+
 /* ---------------------------------------------------------------------------------------------
  * Weight packing.  Source: fp32 parameter in torch layout.  Destination: the MFMA operand image
  * [cout_block][k_block][tap][quarter][cout_in_block][16 bytes] consumed by the igemm kernels.
@@ -208,6 +217,10 @@ int msseg_deconv_k2s2_wgrad(const void* x, long long ldx, const void* dy, long l
  * ------------------------------------------------------------------------------------------- */
 int msseg_dwconv3d_k3_fwd(const void* x, long long ldx, const void* w_taps, const float* bias, void* y, long long ldy, int N,
                           int D, int H, int W, int C, int flip, int dtype, msseg_stream_t stream);
+/* nn.AvgPool3d(kernel_size=3, stride=1, padding=1), count_include_pad (models/backbones/swinception.py:113-116): the same
+ * kernel with unit taps, the fp32 sum scaled by 1/27 before the one rounding to the tensors' dtype; self-adjoint. */
+int msseg_avgpool3d_k3(const void* x, long long ldx, void* y, long long ldy, int N, int D, int H, int W, int C, int dtype,
+                       msseg_stream_t stream);
 int msseg_dwconv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, float* dbias,
                             int accumulate_w, int accumulate_b, int N, int D, int H, int W, int C, void* scratch,
                             size_t scratch_bytes, int dtype, msseg_stream_t stream);
@@ -432,6 +445,25 @@ int msseg_argmax_u8(const float* logits, int C, long long V, uint8_t* out, msseg
 int msseg_resample_nearest_u8(const uint8_t* src, int SD, int SH, int SW, uint8_t* dst, int TD, int TH, int TW,
                               msseg_stream_t stream);
 int msseg_majority_vote_u8(const uint8_t* labels, int F, long long V, int C, uint8_t* out, msseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hausdorff-95 of eval_model (engine/test.py:31,48-51,64: MONAI HausdorffDistanceMetric(include_background=True,
+ * percentile=95, reduction="mean", get_not_nans=True)).  Exact integer work on uint8 label maps [D][H][W]:
+ * hd_edges: surface voxels (6-neighbour erosion XOR, outside = background) of both maps for all classes: edge maps hold
+ *            the class on surface voxels and 0xFF elsewhere; stats[c][8] = {min z, y, x, max z, y, x (inclusive) of class
+ *            c's surface voxels of BOTH maps, #surface voxels of pred, of gt}.
+ * hd_directed_hist: hist[d2] = number of class-`cls` surface voxels of `edges_tgt` whose squared Euclidean distance (voxel
+ *            units) to the nearest class-`cls` surface voxel of `edges_src` is d2, searched inside box6 = {z0, y0, x0, z1,
+ *            y1, x1} (half-open; must contain both surfaces: hd_edges' box); bin nbins-1 counts voxels with no source voxel.
+ *            nbins >= (bz-1)^2 + (by-1)^2 + (bx-1)^2 + 2.  The caller takes the percentile's order statistics from the
+ *            histogram and the square roots in double (scipy.ndimage.distance_transform_edt's values).
+ * ------------------------------------------------------------------------------------------- */
+int msseg_hd_edges(const uint8_t* pred, const uint8_t* gt, int D, int H, int W, int C, uint8_t* edges_pred,
+                   uint8_t* edges_gt, int* stats, msseg_stream_t stream);
+size_t msseg_hd_directed_workspace_bytes(int bz, int by, int bx);
+int msseg_hd_directed_hist(const uint8_t* edges_src, const uint8_t* edges_tgt, int cls, int D, int H, int W,
+                           const int* box6, void* workspace, size_t workspace_bytes, int* hist, int nbins,
+                           msseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-side training crop + augmentation (the step right before the path): one gather launch per

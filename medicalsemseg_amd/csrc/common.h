@@ -28,6 +28,17 @@ void msseg_set_error(const char* fmt, ...);
         if (e__ != hipSuccess) MSSEG_FAIL(MSSEG_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)
 
+// ---- optional event pair around ONE kernel launch (ktimer.hip; bench.py's per-kernel roofline) -------
+bool msseg_ktimer_on();
+int msseg_ktimer_begin(const char* name, hipStream_t stream);
+void msseg_ktimer_end(int slot, hipStream_t stream);
+#define MSSEG_KTIMED(name, stream, launch_stmt)                               \
+    do {                                                                      \
+        const int kt__ = msseg_ktimer_on() ? msseg_ktimer_begin(name, stream) : -1; \
+        launch_stmt;                                                          \
+        if (kt__ >= 0) msseg_ktimer_end(kt__, stream);                        \
+    } while (0)
+
 // ---- dynamic LDS above 64 KB ---------------------------------------------------
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of a (kernel, device) pair.  One of these lives as a
 // function-local static next to each kernel instantiation: a bit per device ordinal, set after the first successful

@@ -1,8 +1,9 @@
 // conv3d 3x3x3 (stride 1, pad 1) on channels-last bf16 -- "ping-pong" implicit GEMM for gfx950.
 //
-// Replaces torch's Conv3d inside MONAI's Convolution block (reference: models/unet.py -> monai BasicUNet TwoConv,
-// /root/reference/models/model_builder.py:46-58) for the layers with 32 input channels per stage: the 96^3 / 48^3
-// levels that hold ~85 % of the network's FLOPs.
+// Replaces torch's Conv3d inside MONAI's Convolution block: MONAI BasicUNet's TwoConv (BASELINE.json configs 1-3; the
+// reference ships no UNet, SURVEY.md row A15 -- here medicalsemseg_amd/models/unet.py) and the 3x3x3 convolutions of
+// UnetResBlock in the reference's UNETR decoder (/root/reference/models/segmentors/swin_unetr.py:73-128), for the layers
+// with 32 input channels per stage: the 96^3 / 48^3 levels that hold ~85 % of the UNet's FLOPs.
 //
 // One persistent workgroup of 8 waves per CU, split into two groups of 4 waves (one wave per SIMD each).  The groups
 // work on different output tiles and alternate roles every phase:
@@ -370,7 +371,7 @@ template <int STATS, int TIMING> int launch(const K3ppParams& p, hipStream_t str
     gx &= ~7;
     if (gx < 8) gx = 8;
     if (gx > tiles) gx = tiles;
-    hipLaunchKernelGGL(kern, dim3(gx, ncb, 1), dim3(NTHREADS), lds, stream, p);
+    MSSEG_KTIMED("k3pp_kernel", stream, hipLaunchKernelGGL(kern, dim3(gx, ncb, 1), dim3(NTHREADS), lds, stream, p));
     MSSEG_CHECK_LAUNCH("conv3d_k3_pp");
     if (STATS != 0) {
         K3FinParams f{};

@@ -317,7 +317,7 @@ int msseg_k3wg_pp_launch(const K3WgParams& p, int gx, hipStream_t stream) {
         MSSEG_FAIL(MSSEG_ELAUNCH, "conv3d_k3_wgrad_pp: cannot set dynamic LDS size %d", lds);
     const int pairs = ceil_div(p.M, 32) * ceil_div(p.K, 32);
     if (timing) hipLaunchKernelGGL(k3wg_pp_kernel<1>, dim3(gx, pairs, 1), dim3(NTHREADS), lds, stream, pl);
-    else hipLaunchKernelGGL(k3wg_pp_kernel<0>, dim3(gx, pairs, 1), dim3(NTHREADS), lds, stream, pl);
+    else MSSEG_KTIMED("k3wg_pp_kernel", stream, hipLaunchKernelGGL(k3wg_pp_kernel<0>, dim3(gx, pairs, 1), dim3(NTHREADS), lds, stream, pl));
     MSSEG_CHECK_LAUNCH("conv3d_k3_wgrad_pp");
     return MSSEG_OK;
 }

@@ -48,6 +48,7 @@ struct DwParams {
     void* y; long long ldy;
     int N, D, H, W, C;
     int flip;              // 1: taps mirrored (input gradient)
+    float out_scale;       // w == null: every tap is 1 and the fp32 sum is scaled by this (AvgPool3d(3, 1, 1): 1 / 27)
 };
 
 template <typename T>
@@ -80,7 +81,12 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(const DwParams p) {
                     const bool ok = okh && (unsigned)(w0 + kw - 1) < (unsigned)p.W;
                     const int tap = (kd * 3 + kh) * 3 + kw;
                     float wt[E];
-                    Chunk<T>::load((const T*)p.w + (long long)(p.flip ? 26 - tap : tap) * p.C + c0, wt);
+                    if (p.w) {
+                        Chunk<T>::load((const T*)p.w + (long long)(p.flip ? 26 - tap : tap) * p.C + c0, wt);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) wt[e] = 1.f;
+                    }
                     const long long nv = ok ? v + ((long long)(kd - 1) * p.H + (kh - 1)) * p.W + (kw - 1) : v;
                     float xv[E];
                     Chunk<T>::load(xg + nv * p.ldx + c0, xv);
@@ -89,6 +95,10 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(const DwParams p) {
                     for (int e = 0; e < E; ++e) acc[e] = fmaf(xv[e] * m, wt[e], acc[e]);
                 }
             }
+        }
+        if (!p.w) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] *= p.out_scale;
         }
         Chunk<T>::store(yg + v * p.ldy + c0, acc);
     }
@@ -219,6 +229,18 @@ int check(const void* x, long long ldx, const void* y, long long ldy, int N, int
     return MSSEG_OK;
 }
 
+int launch_dw(const DwParams& p, int dtype, msseg_stream_t stream) {
+    const int N = p.N, D = p.D, H = p.H, W = p.W, C = p.C;
+    const long long total = (long long)N * D * H * W * (C / (dtype == MSSEG_F32 ? 4 : 8));
+    long long gx = (total + 255) / 256;
+    const long long cap = (long long)msseg_num_cus() * 16;
+    if (gx > cap) gx = cap;
+    if (dtype == MSSEG_F32) hipLaunchKernelGGL(dwconv3_kernel<float>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(dwconv3_kernel<bf16_t>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, p);
+    MSSEG_CHECK_LAUNCH("dwconv3d_k3_fwd");
+    return MSSEG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -228,15 +250,14 @@ int msseg_dwconv3d_k3_fwd(const void* x, long long ldx, const void* w_taps, cons
     int rc = check(x, ldx, y, ldy, N, D, H, W, C, dtype, "dwconv3d_k3_fwd");
     if (rc) return rc;
     if (!w_taps || ((uintptr_t)w_taps & 15)) MSSEG_FAIL(MSSEG_EINVAL, "dwconv3d_k3_fwd: weight table must be 16-byte aligned");
-    DwParams p{x, ldx, w_taps, bias, y, ldy, N, D, H, W, C, flip ? 1 : 0};
-    const long long total = (long long)N * D * H * W * (C / (dtype == MSSEG_F32 ? 4 : 8));
-    long long gx = (total + 255) / 256;
-    const long long cap = (long long)msseg_num_cus() * 16;
-    if (gx > cap) gx = cap;
-    if (dtype == MSSEG_F32) hipLaunchKernelGGL(dwconv3_kernel<float>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(dwconv3_kernel<bf16_t>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, p);
-    MSSEG_CHECK_LAUNCH("dwconv3d_k3_fwd");
-    return MSSEG_OK;
+    return launch_dw(DwParams{x, ldx, w_taps, bias, y, ldy, N, D, H, W, C, flip ? 1 : 0, 1.f}, dtype, stream);
+}
+
+int msseg_avgpool3d_k3(const void* x, long long ldx, void* y, long long ldy, int N, int D, int H, int W, int C, int dtype,
+                       msseg_stream_t stream) {
+    int rc = check(x, ldx, y, ldy, N, D, H, W, C, dtype, "avgpool3d_k3");
+    if (rc) return rc;
+    return launch_dw(DwParams{x, ldx, nullptr, nullptr, y, ldy, N, D, H, W, C, 0, 1.f / 27.f}, dtype, stream);
 }
 
 int msseg_dwconv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, float* dbias,

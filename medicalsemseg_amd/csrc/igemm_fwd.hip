@@ -727,7 +727,10 @@ int launch_cfg(IgemmParams& p, hipStream_t stream) {
     if (gx > p.ntiles) gx = p.ntiles;
     if (gx < 1) gx = 1;
     dim3 grid(gx, ncb, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, stream, p);
+    static const char* const kt_name = NTAPS != 27 ? "igemm_fwd_kernel<flat>"
+                                       : (TD * TH * TW == 512 ? "igemm_fwd_kernel<27,4x8x16>"
+                                          : (TD * TH * TW == 128 ? "igemm_fwd_kernel<27,4x4x8>" : "igemm_fwd_kernel<27,2x4x8>"));
+    MSSEG_KTIMED(kt_name, stream, hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, stream, p));
     MSSEG_CHECK_LAUNCH("igemm_fwd");
     if (EPI == EPI_STORE && p.stats != nullptr) {
         K3FinParams f{};

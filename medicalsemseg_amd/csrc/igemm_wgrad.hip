@@ -532,7 +532,8 @@ int launch_wg(WgradParams& p, ReduceParams& rp, void* workspace, size_t ws_bytes
     auto kern = igemm_wgrad_kernel<T, NTAPS, QSRC, TD, TH, TW>;
     static msseg_lds_attr_once attr;
     if (!attr.ensure((const void*)kern, C::LDS_BYTES)) MSSEG_FAIL(MSSEG_ELAUNCH, "wgrad: cannot set dynamic LDS size %d", C::LDS_BYTES);
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, pairs, 1), dim3(256), C::LDS_BYTES, stream, p);
+    MSSEG_KTIMED(NTAPS == 27 ? "igemm_wgrad_kernel<27>" : "igemm_wgrad_kernel<flat>", stream,
+                 hipLaunchKernelGGL(kern, dim3((unsigned)gx, pairs, 1), dim3(256), C::LDS_BYTES, stream, p));
     MSSEG_CHECK_LAUNCH("igemm_wgrad");
     rp.slabs = p.slabs;
     rp.mblks = p.mblks; rp.kblks = p.kblks; rp.nslots = (int)gx * wave_slots; rp.cbw = C::CBW;

@@ -3,7 +3,8 @@
 the reference's softmax is monotonic) and resampled to the original grid with ``msseg_resample_nearest_u8`` (the
 reference's ``resample_3d`` = scipy order-0 zoom, ``utils/misc.py:420-425``); only uint8 maps cross PCIe.  Outputs go
 to the reference's directory layout as NIfTI-1 files (``utils/nifti.py``: nibabel is not available) when the input names
-carry a NIfTI extension, as ``.npy`` otherwise (synthetic loaders).  Hausdorff95 is outside the hot path."""
+carry a NIfTI extension, as ``.npy`` otherwise (synthetic loaders).  The Hausdorff-95 meter (``mHdorffDist``, :20,31,48-51,64)
+comes from ``metrics.hausdorff95``: surfaces, exact distances and their histogram on the device."""
 from __future__ import annotations
 
 import os
@@ -11,7 +12,7 @@ import os
 import numpy as np
 import torch
 
-from .. import hip
+from .. import hip, metrics
 from ..utils import misc
 from .train import _metric_update
 from .utils import sliding_window_inference
@@ -27,7 +28,7 @@ def eval_model(inferer, model, data_loader, criterion, device, cfg, log_writer=N
     None for the built-in sliding window with the validation settings.  Returns {'eval/<meter>': global average}."""
     model.eval()
     metric_logger = misc.MetricLogger(delimiter="  ")
-    for name in ["loss", "mDice"] + ["class" + str(c) + "Dice" for c in range(cfg.output_dim)]:
+    for name in ["loss", "mHdorffDist", "mDice"] + ["class" + str(c) + "Dice" for c in range(cfg.output_dim)]:
         metric_logger.add_meter(name, misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))
     header = "Evaluation starting"
     for data_iter_step, batch in enumerate(metric_logger.log_every(data_loader, 1, header)):
@@ -46,7 +47,10 @@ def eval_model(inferer, model, data_loader, criterion, device, cfg, log_writer=N
                     w if isinstance(w, (tuple, list)) else (w, None, aff_xyz)))
             loss = criterion(outputs, labels)
         mDice = _metric_update(metric_logger, criterion, outputs, labels, cfg.output_dim)
-        metric_logger.update(loss=loss.item(), mDice=mDice.item())
+        # engine/test.py:31,48-51: Hausdorff-95 of the arg-max map against the labels, all classes, MONAI's "mean" reduction
+        pred_maps = torch.stack([label_map(outputs[b:b + 1]) for b in range(outputs.shape[0])])
+        hdorf, _ = metrics.hausdorff_mean(metrics.hausdorff95(pred_maps, labels, cfg.output_dim))
+        metric_logger.update(loss=loss.item(), mHdorffDist=hdorf, mDice=mDice.item())
         if getattr(cfg, "save_eval_output", False) and cfg.output_dir:
             os.makedirs(cfg.output_dir, exist_ok=True)
             np.save(os.path.join(cfg.output_dir, "pred_" + img_name + ".npy"), label_map(outputs).cpu().numpy())

@@ -114,6 +114,14 @@ SIGNATURES = {
     "msseg_aug_crop_batch": ([_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp], _i),
     "msseg_sw_gather_batch": ([_vp, _ll, _vp, _ll, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
     "msseg_sw_blend_batch": ([_vp, _ll, _i, _vp, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_avgpool3d_k3": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_hd_edges": ([_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
+    "msseg_hd_directed_workspace_bytes": ([_i, _i, _i], _sz),
+    "msseg_hd_directed_hist": ([_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _i, _vp], _i),
+    "msseg_ktimer_enable": ([_i], _i),
+    "msseg_ktimer_reset": ([], _i),
+    "msseg_ktimer_count": ([], _i),
+    "msseg_ktimer_get": ([_i, C.c_char_p, _i, C.POINTER(C.c_float)], _i),
 }
 
 
@@ -139,7 +147,10 @@ def load_library(path: Optional[str] = None):
 
 
 def lib():
-    return _lib if _lib is not None else load_library()
+    real = _lib if _lib is not None else load_library()
+    if TIMER.enabled:
+        return _TimedLib(real)
+    return real
 
 
 class MssegError(RuntimeError):
@@ -192,6 +203,11 @@ def ld(t: torch.Tensor) -> int:
     if l < C:
         raise ValueError("voxel stride smaller than the channel count")
     return l
+
+
+def _nbytes(*ts) -> float:
+    """algorithmic bytes of a streaming pass: every operand read or written once"""
+    return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -283,20 +299,36 @@ def pack_deconv(w: torch.Tensor, dtype, bwd=False, out=None):
 # optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg)
 # --------------------------------------------------------------------------------------------
 class KernelTimer:
-    """Collects (start, end, flops, bytes) per launch of the kernels it is asked to watch."""
+    """Per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  While `enabled`, EVERY call into
+    the library that launches kernels is bracketed by an event pair and filed under its entry point's name (`lib()` hands
+    out a timing proxy), so the dominant group of a step is found by measurement; `launch()` lets a wrapper file a call
+    under its own key with the call's algorithmic flops / bytes.  An entry point's time includes the small follow-up
+    kernels it launches itself (statistics finalize, slab reduction); the main kernels' own durations come from the
+    library's `msseg_ktimer_*` events, recorded directly around those launches (`ktimer_summary`)."""
 
     def __init__(self):
         self.records = {}
         self.enabled = False
+        self._pending = None
 
     def launch(self, key, flops, nbytes, fn):
         if not self.enabled:
             return fn()
+        self._pending = (key, flops, nbytes)
+        try:
+            return fn()
+        finally:
+            self._pending = None
+
+    def call(self, name, cfn, args):
+        ann, self._pending = self._pending, None
+        key, flops, nbytes = ann if ann is not None else (name[6:], 0.0, 0.0)
+        st = torch.cuda.current_stream()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(torch.cuda.current_stream())
-        r = fn()
-        e1.record(torch.cuda.current_stream())
+        e0.record(st)
+        r = cfn(*args)
+        e1.record(st)
         self.records.setdefault(key, []).append((e0, e1, flops, nbytes))
         return r
 
@@ -307,6 +339,44 @@ class KernelTimer:
             out[k] = {"launches": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
                       "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs)}
         return out
+
+
+class _TimedLib:
+    """what `lib()` returns while TIMER.enabled: every launching entry point goes through TIMER.call"""
+    _QUERY = ("_bytes", "_block", "_variant", "_kernel", "abi_version", "last_error", "num_cus")
+
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if name.endswith(self._QUERY) or name.startswith("msseg_ktimer"):
+            return fn
+        return lambda *a: TIMER.call(name, fn, a)
+
+
+def ktimer_enable(on: bool):
+    """library-side event pairs directly around the main conv kernels (msseg_ktimer_*, include/msseg.h)"""
+    load_library().msseg_ktimer_enable(int(on))
+
+
+def ktimer_summary(reset=True):
+    """{kernel name: {"launches", "total_ms", "avg_ms"}} of the launches recorded since the last reset (synchronises)"""
+    L = load_library()
+    torch.cuda.synchronize()
+    out = {}
+    buf = C.create_string_buffer(96)
+    ms = C.c_float()
+    for i in range(L.msseg_ktimer_count()):
+        if L.msseg_ktimer_get(i, buf, 96, C.byref(ms)) == 0:
+            r = out.setdefault(buf.value.decode(), {"launches": 0, "total_ms": 0.0})
+            r["launches"] += 1
+            r["total_ms"] += float(ms.value)
+    for r in out.values():
+        r["avg_ms"] = r["total_ms"] / r["launches"]
+    if reset:
+        L.msseg_ktimer_reset()
+    return out
 
 
 TIMER = KernelTimer()
@@ -546,7 +616,10 @@ def conv3d_k3_wgrad(x, dy, dw, cin, cout, accumulate=False):
     def go():
         _ck(lib().msseg_conv3d_k3_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), N, D, H, W, cin, cout, int(accumulate),
                                         _p(ws), ws.numel(), dt(x), _stream()), "conv3d_k3_wgrad")
-    TIMER.launch("conv3d_k3_wgrad", 2.0 * nv * 27 * cin * cout, nv * (cin + cout) * x.element_size() + 27 * cin * cout * 4, go)
+    key = "conv3d_k3_wgrad"
+    if TIMER.enabled:
+        key += "/v%d" % lib().msseg_conv3d_k3_wgrad_kernel(N, D, H, W, cin, cout, dt(x))
+    TIMER.launch(key, 2.0 * nv * 27 * cin * cout, nv * (cin + cout) * x.element_size() + 27 * cin * cout * 4, go)
 
 
 def conv3d_k1_wgrad(x, dy, dw, cin, cout, accumulate=False):
@@ -589,6 +662,14 @@ def dwconv3d_k3(x, w_taps, bias, y, flip=False):
     N, D, H, W, C = x.shape
     _ck(lib().msseg_dwconv3d_k3_fwd(_p(x), ld(x), _p(w_taps), _p(bias), _p(y), ld(y), N, D, H, W, C, int(flip), dt(x),
                                     _stream()), "dwconv3d_k3_fwd")
+    return y
+
+
+def avgpool3d_k3(x, y):
+    """AvgPool3d(3, 1, 1) with count_include_pad: fp32 sum of the 27 taps x 1/27, one rounding"""
+    _need_gpu(x, y)
+    N, D, H, W, Cc = x.shape
+    _ck(lib().msseg_avgpool3d_k3(_p(x), ld(x), _p(y), ld(y), N, D, H, W, Cc, dt(x), _stream()), "avgpool3d_k3")
     return y
 
 
@@ -667,9 +748,9 @@ def channel_stats(x, stats=None):
 def instnorm_act_fwd(x, stats, gamma, beta, y, slope, eps=1e-5, residual=None):
     _need_gpu(x, stats, y)
     N, S, Cc = _nsc(x)
-    _ck(lib().msseg_instnorm_act_fwd(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(residual),
+    TIMER.launch("instnorm_act_fwd", 0.0, _nbytes(x, y, residual), lambda: _ck(lib().msseg_instnorm_act_fwd(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(residual),
                                      ld(residual) if residual is not None else 0, _p(y), ld(y), N, S, Cc, eps, slope,
-                                     dt(x), _stream()), "instnorm_act_fwd")
+                                     dt(x), _stream()), "instnorm_act_fwd"))
     return y
 
 
@@ -684,8 +765,8 @@ def instnorm_act_pool_fwd(x, stats, gamma, beta, y, pooled, slope, eps=1e-5):
     """y = lrelu(instance_norm(x)) and pooled = max_pool3d(y, 2) in one pass over x (channels-last [N, D, H, W, C])"""
     _need_gpu(x, stats, y, pooled)
     N, D, H, W, Cc = x.shape
-    _ck(lib().msseg_instnorm_act_pool_fwd(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(y), ld(y), _p(pooled), ld(pooled),
-                                          N, D, H, W, Cc, eps, slope, dt(x), _stream()), "instnorm_act_pool_fwd")
+    TIMER.launch("instnorm_act_pool_fwd", 0.0, _nbytes(x, y, pooled), lambda: _ck(lib().msseg_instnorm_act_pool_fwd(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(y), ld(y), _p(pooled), ld(pooled),
+                                          N, D, H, W, Cc, eps, slope, dt(x), _stream()), "instnorm_act_pool_fwd"))
     return y, pooled
 
 
@@ -697,10 +778,10 @@ def instnorm_act_poolbwd_reduce(x, stats, gamma, beta, skip, g, da, slope, eps=1
     N, D, H, W, Cc = x.shape
     red = torch.empty(N, Cc, 2, dtype=torch.float32, device=x.device)
     sc = scratch(x.device)
-    _ck(lib().msseg_instnorm_act_poolbwd_reduce(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(skip), ld(skip), _p(g),
+    TIMER.launch("instnorm_act_poolbwd_reduce", 0.0, _nbytes(x, skip, g, da), lambda: _ck(lib().msseg_instnorm_act_poolbwd_reduce(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(skip), ld(skip), _p(g),
                                                 ld(g), _p(da), ld(da), _p(red), _p(dgamma), _p(dbeta), int(accumulate),
                                                 N, D, H, W, Cc, eps, slope, _p(sc), sc.numel(), dt(x), _stream()),
-        "instnorm_act_poolbwd_reduce")
+        "instnorm_act_poolbwd_reduce"))
     return red
 
 
@@ -720,10 +801,10 @@ def instnorm_act_bwd_reduce(x, stats, gamma, y, dy, slope, eps=1e-5, dgamma=None
     N, S, Cc = _nsc(x)
     red = torch.empty(N, Cc, 2, dtype=torch.float32, device=x.device)
     sc = scratch(x.device)
-    _ck(lib().msseg_instnorm_act_bwd_reduce(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(y),
+    TIMER.launch("instnorm_act_bwd_reduce", 0.0, _nbytes(x, y, dy), lambda: _ck(lib().msseg_instnorm_act_bwd_reduce(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(y),
                                             ld(y) if y is not None else 0, _p(dy), ld(dy), _p(red),
                                             _p(dgamma), _p(dbeta), int(accumulate), N, S, Cc, eps, slope, _p(sc),
-                                            sc.numel(), dt(x), _stream()), "instnorm_act_bwd_reduce")
+                                            sc.numel(), dt(x), _stream()), "instnorm_act_bwd_reduce"))
     return red
 
 
@@ -731,10 +812,10 @@ def instnorm_act_bwd_apply(x, stats, gamma, y, dy, red, dx, slope, eps=1e-5, dre
     """y None: the sign of the pre-activation is recomputed from x (layers without residual)"""
     _need_gpu(x, stats, dy, dx, red)
     N, S, Cc = _nsc(x)
-    _ck(lib().msseg_instnorm_act_bwd_apply(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(y),
+    TIMER.launch("instnorm_act_bwd_apply", 0.0, _nbytes(x, y, dy, dx, dres), lambda: _ck(lib().msseg_instnorm_act_bwd_apply(_p(x), ld(x), _p(stats), _p(gamma), _p(beta), _p(y),
                                            ld(y) if y is not None else 0, _p(dy), ld(dy), _p(red),
                                            _p(dx), ld(dx), _p(dres), ld(dres) if dres is not None else 0, N, S, Cc, eps,
-                                           slope, dt(x), _stream()), "instnorm_act_bwd_apply")
+                                           slope, dt(x), _stream()), "instnorm_act_bwd_apply"))
     return red
 
 
@@ -952,6 +1033,31 @@ def majority_vote_u8(labels: torch.Tensor, n_classes: int) -> torch.Tensor:
     _ck(lib().msseg_majority_vote_u8(_p(labels), labels.shape[0], out.numel(), n_classes, _p(out), _stream()),
         "majority_vote_u8")
     return out
+
+
+def hd_edges(pred: torch.Tensor, gt: torch.Tensor, n_classes: int):
+    """pred / gt: uint8 label maps [D, H, W] -> (edge map of pred, edge map of gt, stats int32 [n_classes, 8])"""
+    _need_gpu(pred, gt)
+    assert pred.dtype == torch.uint8 and gt.dtype == torch.uint8 and pred.shape == gt.shape and pred.dim() == 3
+    pred, gt = pred.contiguous(), gt.contiguous()
+    D, H, W = pred.shape
+    ep, eg = torch.empty_like(pred), torch.empty_like(gt)
+    stats = torch.empty(n_classes, 8, dtype=torch.int32, device=pred.device)
+    _ck(lib().msseg_hd_edges(_p(pred), _p(gt), D, H, W, n_classes, _p(ep), _p(eg), _p(stats), _stream()), "hd_edges")
+    return ep, eg, stats
+
+
+def hd_directed_hist(edges_src, edges_tgt, cls: int, box, hist: torch.Tensor):
+    """histogram (int32, on the device) of the squared distances from the class-`cls` surface voxels of edges_tgt to the
+    nearest class-`cls` surface voxel of edges_src inside box = (z0, y0, x0, z1, y1, x1); the last bin counts 'no source'"""
+    _need_gpu(edges_src, edges_tgt, hist)
+    D, H, W = edges_src.shape
+    bz, by, bx = box[3] - box[0], box[4] - box[1], box[5] - box[2]
+    ws = workspace(lib().msseg_hd_directed_workspace_bytes(bz, by, bx), edges_src.device)
+    b6 = (C.c_int * 6)(*[int(v) for v in box])
+    _ck(lib().msseg_hd_directed_hist(_p(edges_src), _p(edges_tgt), int(cls), D, H, W, b6, _p(ws), ws.numel(), _p(hist),
+                                     hist.numel(), _stream()), "hd_directed_hist")
+    return hist
 
 
 def aug_crop_batch(img, lab, table, out_img, out_lab, roi):

@@ -652,8 +652,23 @@ class BatchNormAct:
                         bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
                         bn.running_var.mul_(1 - bn.momentum).add_(var, alpha=bn.momentum)
         else:
-            rm, rv = bn.running_mean.float(), bn.running_var.float()
-            s = torch.stack([rm * cnt, (rv + rm * rm) * cnt], -1).unsqueeze(0).contiguous()
+            # Eval mode: y = x * scale + shift with scale = gamma / sqrt(running_var + eps), shift = beta - running_mean *
+            # scale, formed in double.  The kernel normalises with (mean, var) it derives from sums as E[x^2] - mean^2; handing
+            # it sums rebuilt from the running statistics would cancel catastrophically when mean^2 >> var (mean 10, var
+            # 1e-2: 1e-3 relative error in rstd).  Instead it gets the sums of a zero-mean, (1 - eps)-variance channel --
+            # mean 0 and rstd 1 come out exactly -- and the folded scale / shift as its affine parameters.
+            eps = self.inner.eps
+            rstd = torch.rsqrt(bn.running_var.double() + eps)
+            g = self.inner.gamma.detach().double() if self.inner.gamma is not None else torch.ones_like(rstd)
+            bta = self.inner.beta.detach().double() if self.inner.beta is not None else torch.zeros_like(rstd)
+            scale = g * rstd
+            shift = bta - bn.running_mean.double() * scale
+            s = torch.zeros(1, C, 2, dtype=torch.float32, device=y_raw.device)
+            s[0, :, 1] = (1.0 - eps) * cnt
+            a = out if out is not None else torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device)
+            hip.instnorm_act_fwd(_merge_batch(y_raw), s, scale.float().contiguous(), shift.float().contiguous(),
+                                 _merge_batch(a), self.inner.slope, eps, None)
+            return a, s
         a = out if out is not None else torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device)
         hip.instnorm_act_fwd(_merge_batch(y_raw), s, self.inner.gamma, self.inner.beta, _merge_batch(a), self.inner.slope,
                              self.inner.eps, None)

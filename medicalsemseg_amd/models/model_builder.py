@@ -9,6 +9,8 @@ for the models on the hot path.
   branch at ``model_builder.py:120-171``.
 * ``cfg.model == 'SwInception'`` -- the same wiring around the ``SwInception`` encoder (Inception-head MLP: Conv3d +
   BatchNorm3d + GELU branches with 6- / 38-channel convolutions at width 48), the branch at ``model_builder.py:67-119``.
+* ``cfg.model == 'SwinSegFormer'`` -- ``SwinTransformerNNFormer`` + the progressive-fusion ``SegFormerHead``
+  (``model_builder.py:173-189``, ``models/segmentors/segformer_head.py``).
 * ``cfg.model == 'SegFormer3D'`` -- ``MixVisionTransformer`` + ``SegFormerHeadOfficial`` (``model_builder.py:190-205``).
 * ``cfg.model == 'SwinUNETR'`` -- the vendored MONAI variant of ``models/segmentors/swin_unetr_official.py`` (window 7,
   ``feature_size = cfg.hidden_dim``), the literal "Swin-UNETR 48-feat" of BASELINE.json configs[3] (the reference keeps
@@ -22,7 +24,7 @@ import torch
 
 from .unet import UNET_FEATURES, UNet
 
-OUT_OF_SCOPE = ("SwinSegFormer", "GCViTUNETR", "FocalNetUNETR")
+OUT_OF_SCOPE = ("GCViTUNETR", "FocalNetUNETR")
 
 
 def _dtype(cfg):
@@ -56,6 +58,20 @@ def build_model(cfg):
         return SwinUNETRCustom(encoder, in_channels=cfg.in_chans, out_channels=cfg.output_dim,
                                img_size=_t3(cfg.vol_size), hidden_size=cfg.hidden_dim, patch_size=_t3(cfg.patch_size),
                                compute_dtype=_dtype(cfg))
+    if name == "SwinSegFormer":                                 # model_builder.py:173-189
+        from .segformer3d import SegFormerHead
+        from .swin_unetr import SwinTransformerNNFormer
+        if getattr(cfg, "abs_pos_emb", False):
+            raise NotImplementedError("--abs_pos_emb is outside the hot-path scope of this build (SURVEY.md section 2)")
+        if len(cfg.depths) != 4:
+            raise ValueError("SwinSegFormer's head fuses five feature maps: a four-stage encoder (--depths a b c d)")
+        ws = cfg.window_size if isinstance(cfg.window_size, (tuple, list)) else (cfg.window_size,) * len(cfg.depths)
+        encoder = SwinTransformerNNFormer(pretrain_img_size=_t3(cfg.vol_size), patch_size=_t3(cfg.patch_size),
+                                          in_chans=cfg.in_chans, embed_dim=cfg.hidden_dim, depths=tuple(cfg.depths),
+                                          num_heads=tuple(cfg.num_heads), window_size=tuple(ws), qkv_bias=cfg.qkv_bias,
+                                          compute_dtype=_dtype(cfg))
+        return SegFormerHead(encoder, [cfg.hidden_dim * 2 ** i for i in range(len(cfg.depths) + 1)], cfg.output_dim,
+                             compute_dtype=_dtype(cfg))
     if name == "SegFormer3D":                                   # model_builder.py:190-205
         from .segformer3d import MixVisionTransformer, SegFormerHeadOfficial
         enc = MixVisionTransformer(img_size=cfg.vol_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans,
@@ -69,5 +85,5 @@ def build_model(cfg):
                          num_heads=tuple(cfg.num_heads), feature_size=cfg.hidden_dim, compute_dtype=_dtype(cfg))
     if name in OUT_OF_SCOPE:
         raise NotImplementedError(f"model '{name}' is a research variant outside this build's hot-path scope "
-                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR', 'SwinDepth', 'SwInception', 'SegFormer3D', 'SwinUNETR']")
+                                  f"(SURVEY.md section 2); available: {sorted(UNET_FEATURES)} + ['nnFormerUNETR', 'SwinDepth', 'SwInception', 'SwinSegFormer', 'SegFormer3D', 'SwinUNETR']")
     raise ValueError(f"unknown cfg.model '{name}'")

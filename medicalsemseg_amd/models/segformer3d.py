@@ -200,6 +200,57 @@ class SegFormerHeadOfficial(nn.Module):
         return _PredUpsampleFn.apply(x, self.linear_pred.weight, self.linear_pred.bias, size, self.num_classes, op)
 
 
+class SegFormerHead(nn.Module):
+    """The 'SwinSegFormer' head (``/root/reference/models/segmentors/segformer_head.py:40-121``, wired at
+    ``models/model_builder.py:173-189`` behind the SwinTransformerNNFormer encoder): the five feature maps are fused
+    coarse to fine -- Linear per map, trilinear upsampling to the next finer map, cat([coarse, fine]) -> Conv3d 1x1x1 +
+    BatchNorm3d(eps 1e-3) + GELU -- then Dropout3d and the prediction conv.
+
+    The reference upsamples the fused 512-channel map to the input size BEFORE the dropout and the prediction conv
+    (:107-116).  Channel dropout, a 1x1x1 conv and trilinear interpolation commute (the interpolation weights of a voxel
+    sum to 1, so the bias passes through; the dropout scales whole channels), so here the dropout and the prediction
+    conv run on the c0-resolution map and only the `classes` logits rows are upsampled (``_PredUpsampleFn``): 1/8 of the
+    conv FLOPs at patch 2 and no [B, 512, D, H, W] tensor.  Same state-dict keys as the reference."""
+
+    graph_safe = False
+
+    def __init__(self, encoder, in_channels, num_classes, dropout_ratio=0.1, embedding_dim=512, compute_dtype=torch.bfloat16):
+        super().__init__()
+        if len(in_channels) != 5:
+            raise ValueError("SegFormerHead fuses five feature maps (a four-stage encoder + its patch embedding)")
+        self.encoder, self.num_classes, self.compute_dtype = encoder, num_classes, compute_dtype
+        c0, c1, c2, c3, c4 = in_channels
+        self.linear_c4 = _MLP(c4, embedding_dim)
+        self.linear_c3 = _MLP(c3, embedding_dim)
+        self.linear_c2 = _MLP(c2, embedding_dim)
+        self.linear_c1 = _MLP(c1, embedding_dim)
+        self.linear_c0 = _MLP(c0, embedding_dim)
+        for i in range(4):
+            self.add_module(f"linear_fuse_{i}", _BasicConv3d(embedding_dim * 2, embedding_dim))
+        self.dropout_ratio = float(dropout_ratio)
+        self.linear_pred = nn.Conv3d(embedding_dim, num_classes, kernel_size=1)
+        self.sync_group = None          # SyncBatchNorm group under data parallelism (run_training.py:83)
+        self.dropout_mask = None        # fp32 [B, embedding_dim] of 0 / 1: overrides the Bernoulli draw (tests)
+
+    def forward(self, inputs):
+        vol = inputs[0] if isinstance(inputs, (tuple, list)) else inputs
+        size = tuple(vol.shape[2:])
+        feats, _ = self.encoder(inputs)
+        if len(feats) != 5:
+            raise ValueError(f"SegFormerHead needs five feature maps, the encoder returned {len(feats)}")
+        lin = lambda m, c: ops.linear(c, m.proj.weight, m.proj.bias)
+        x = lin(self.linear_c4, feats[4])
+        for i in (3, 2, 1, 0):
+            f = getattr(self, f"linear_fuse_{i}")
+            cat = ops.upsample_concat(feats[i].shape[1:4], [x, lin(getattr(self, f"linear_c{i}"), feats[i])])
+            x = ops.gelu(ops.batch_norm(ops.linear(cat, f.conv.weight, f.conv.bias), f.bn, self.sync_group))
+        x = ops.dropout3d(x, self.dropout_ratio, self.training, self.dropout_mask)
+        op = getattr(self, "_pred_op", None)
+        if op is None or op.w is not self.linear_pred.weight:
+            op = self._pred_op = Conv1(self.linear_pred.weight, self.linear_pred.bias)
+        return _PredUpsampleFn.apply(x, self.linear_pred.weight, self.linear_pred.bias, size, self.num_classes, op)
+
+
 class _PredUpsampleFn(torch.autograd.Function):
     """linear_pred (1x1x1 conv to the classes) + the final trilinear upsampling to the input size, on 16-byte logits
     rows [.., 8] (segformer_head_official.py:86-90)"""

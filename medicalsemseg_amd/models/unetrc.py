@@ -58,8 +58,8 @@ class _Up:
 
 
 class _Cbr:
-    def __init__(self, conv: _Keyed, bn: nn.BatchNorm3d):
-        self.op = ConvBNAct(Conv3(conv.block.weight, conv.block.bias), BatchNormAct(bn, 0.0))
+    def __init__(self, conv: _Keyed, bn: nn.BatchNorm3d, group=None):
+        self.op = ConvBNAct(Conv3(conv.block.weight, conv.block.bias), BatchNormAct(bn, 0.0, group))
 
     def fwd(self, x, out=None):
         return self.op.fwd(x, out)
@@ -68,10 +68,10 @@ class _Cbr:
         return self.op.bwd(saved, dy, need_dx)
 
 
-def _ops_of(m):
+def _ops_of(m, group=None):
     """op records of a Conv3DBlock / Deconv3DBlock / Single* block or a Sequential of them, in execution order"""
     if isinstance(m, nn.Sequential) and not isinstance(m, _Keyed):
-        return [o for sub in m for o in _ops_of(sub)]
+        return [o for sub in m for o in _ops_of(sub, group)]
     inner = m.block
     if isinstance(inner, nn.ConvTranspose3d):
         return [_Up(m)]
@@ -79,8 +79,8 @@ def _ops_of(m):
         return [m]                               # the 1x1x1 output conv: handled by the caller
     mods = list(inner)
     if isinstance(mods[0].block, nn.ConvTranspose3d):
-        return [_Up(mods[0]), _Cbr(mods[1], mods[2])]
-    return [_Cbr(mods[0], mods[1])]
+        return [_Up(mods[0]), _Cbr(mods[1], mods[2], group)]
+    return [_Cbr(mods[0], mods[1], group)]
 
 
 class UNETRC(nn.Module):
@@ -101,16 +101,18 @@ class UNETRC(nn.Module):
         self.decoder6_upsampler = nn.Sequential(_cbr(512, 256), _cbr(256, 256), _up2(256, 128))
         self.decoder3_upsampler = nn.Sequential(_cbr(256, 128), _cbr(128, 128), _up2(128, 64))
         self.decoder0_header = nn.Sequential(_cbr(128, 64), _cbr(64, 64), _conv(64, output_dim, 1))
+        self.sync_group = None      # SyncBatchNorm group under data parallelism (parallel.convert_sync_batchnorm)
         self._build_ops()
 
     def _build_ops(self):
         head = list(self.decoder0_header)
         self._head = Conv1(head[-1].block.weight, head[-1].block.bias)
         # (first-half branch fed by a token map / the input, second-half chain fed by the level below, channels of a half)
-        self._branch = {"z12": _ops_of(self.decoder12_upsampler), "z9": _ops_of(self.decoder9), "z6": _ops_of(self.decoder6),
-                        "z3": _ops_of(self.decoder3), "x": _ops_of(self.decoder0)}
-        self._trunk = {9: _ops_of(self.decoder9_upsampler), 6: _ops_of(self.decoder6_upsampler),
-                       3: _ops_of(self.decoder3_upsampler), 0: _ops_of(nn.Sequential(*head[:-1]))}
+        g = getattr(self, "sync_group", None)
+        self._branch = {"z12": _ops_of(self.decoder12_upsampler, g), "z9": _ops_of(self.decoder9, g), "z6": _ops_of(self.decoder6, g),
+                        "z3": _ops_of(self.decoder3, g), "x": _ops_of(self.decoder0, g)}
+        self._trunk = {9: _ops_of(self.decoder9_upsampler, g), 6: _ops_of(self.decoder6_upsampler, g),
+                       3: _ops_of(self.decoder3_upsampler, g), 0: _ops_of(nn.Sequential(*head[:-1]), g)}
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)

@@ -317,23 +317,20 @@ class DwConv3Fn(torch.autograd.Function):
 
 
 class AvgPool3Fn(torch.autograd.Function):
-    """nn.AvgPool3d(kernel_size=3, stride=1, padding=1) (count_include_pad: every window divides by 27) on a token volume:
-    the depthwise k3 kernel with the constant weight 1/27 (/root/reference/models/backbones/swinception.py:113-116); the
-    operator is symmetric, so the input gradient is the same launch on dy."""
-
-    @staticmethod
-    def _taps(x):
-        return torch.full((27, x.shape[-1]), 1.0 / 27.0, dtype=x.dtype, device=x.device)
+    """nn.AvgPool3d(kernel_size=3, stride=1, padding=1) (count_include_pad: every window divides by 27) on a token volume
+    (/root/reference/models/backbones/swinception.py:113-116): the depthwise k3 kernel with unit taps and the fp32 sum scaled
+    by 1/27 (`msseg_avgpool3d_k3`; a bf16 tap of 1/27 would be 0.0371094: +0.195 % on every output).  The operator is
+    symmetric, so the input gradient is the same launch on dy."""
 
     @staticmethod
     def forward(ctx, x):
         x = _c(x)
-        return hip.dwconv3d_k3(x, AvgPool3Fn._taps(x), None, torch.empty_like(x))
+        return hip.avgpool3d_k3(x, torch.empty_like(x))
 
     @staticmethod
     def backward(ctx, dy):
         dy = _c(dy)
-        return hip.dwconv3d_k3(dy, AvgPool3Fn._taps(dy), None, torch.empty_like(dy), flip=True)
+        return hip.avgpool3d_k3(dy, torch.empty_like(dy))
 
 
 class BatchNormFn(torch.autograd.Function):

@@ -97,6 +97,38 @@ class GradSync:
         self.opt._gscale.mul_(1.0 / self.ws)
 
 
+def convert_sync_batchnorm(model, group=True) -> int:
+    """What the reference does to every model under DDP (/root/reference/run_training.py:83,
+    ``SyncBatchNorm.convert_sync_batchnorm``): each BatchNorm of the build's models normalises with the statistics of the
+    GLOBAL batch.  Here a BatchNorm lives inside an op record (`layers.BatchNormAct`) or behind a module attribute
+    `sync_group` (SwinDepth / SwInception MLPs, the SegFormer head); this walks the module tree and switches all of them.
+    `group`: a process group, True = the default group, None = back to per-rank statistics.  Returns the number of
+    switched holders (0 for the InstanceNorm / LayerNorm models, which need no exchange)."""
+    from .layers import BatchNormAct
+    net = getattr(model, "module", model)
+    n = 0
+    for m in net.modules():
+        if hasattr(m, "sync_group"):
+            m.sync_group = group
+            n += 1
+        for v in vars(m).values():          # op records are plain attributes (lists / dicts of them) of their module
+            stack = [v]
+            while stack:
+                o = stack.pop()
+                if isinstance(o, BatchNormAct):
+                    o.group = group
+                    n += 1
+                elif isinstance(o, (list, tuple)):
+                    stack.extend(o)
+                elif isinstance(o, dict):
+                    stack.extend(o.values())
+                elif hasattr(o, "op") and not isinstance(o, torch.nn.Module):
+                    stack.append(o.op)
+                elif hasattr(o, "norm") and not isinstance(o, torch.nn.Module):
+                    stack.append(o.norm)
+    return n
+
+
 def all_reduce_mean(x: float) -> float:
     """/root/reference/utils/misc.py:307-315"""
     if world_size() == 1:

@@ -2,8 +2,9 @@
 saves with ``nib.save(nib.Nifti1Image(array, affine), path)`` (``/root/reference/engine/test.py:158-170``); nibabel is not
 available in this image.  Follows the published NIfTI-1.1 header layout (348 bytes + 4 extension bytes, data at offset
 352, little endian): the affine goes to the sform rows with ``sform_code = 2`` (aligned), the quaternion fields are filled
-from the same affine with ``qform_code = 0`` -- what ``Nifti1Image(array, affine)`` writes.  Host-side I/O: out of the GPU
-hot path."""
+from the same affine with ``qform_code = 0``.  The output is a valid NIfTI-1 file that readers place like the
+reference's (same affine, dims, dtype); byte-for-byte equality with nibabel's header is NOT claimed (parity unpinned:
+nibabel is absent and no reference fixture holds a header).  Host-side I/O: out of the GPU hot path."""
 from __future__ import annotations
 
 import gzip
@@ -68,7 +69,7 @@ def save_nifti(path: str, array, affine) -> None:
     hdr += struct.pack("<8f", *pixdim)
     hdr += struct.pack("<f", 352.0)                                   # vox_offset
     hdr += struct.pack("<2f", float("nan"), float("nan"))             # scl_slope, scl_inter: "no scaling", as nibabel leaves them
-    hdr += struct.pack("<hBB", 0, 0, 10)                              # slice_end, slice_code, xyzt_units (mm + sec)
+    hdr += struct.pack("<hBB", 0, 0, 0)                               # slice_end, slice_code, xyzt_units (unknown: nothing here knows the units)
     hdr += struct.pack("<4f", 0.0, 0.0, 0.0, 0.0)                     # cal_max, cal_min, slice_duration, toffset
     hdr += struct.pack("<2i", 0, 0)                                   # glmax, glmin
     hdr += struct.pack("<80s24s", b"", b"")                           # descrip, aux_file

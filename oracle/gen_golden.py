@@ -25,8 +25,8 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 sys.path.insert(0, REPO)
-from tests.golden_util import (SEGFORMER_CFG, SW_CASES, UNETRC_PROBES, ToyTokenEncoder, det_fill_, det_tensor, probe,  # noqa: E402
-                               sw_predictor)
+from tests.golden_util import (SEGFORMER_CFG, SW_CASES, SWIN_SEGFORMER_CFG, UNETRC_PROBES, ToyTokenEncoder, det_fill_,  # noqa: E402
+                               det_tensor, probe, sw_predictor)
 
 
 def _install_import_shims():
@@ -243,6 +243,66 @@ def gen_segformer3d():
     _save("segformer3d_ref.npz", **out)
 
 
+def gen_swin_segformer(ref):
+    """the reference's 'SwinSegFormer' branch (models/model_builder.py:173-189): SwinTransformerNNFormer encoder +
+    models/segmentors/segformer_head.py SegFormerHead (progressive fusion of the five feature maps: Linear per map,
+    trilinear x2, Conv3d 1x1x1 + BatchNorm3d(eps 1e-3) + GELU per level, Dropout3d, prediction conv at full resolution) in
+    TRAINING mode with dropout 0 and stochastic depth 0: logits, gradient probes, running statistics, eval logits"""
+    import models.segmentors.segformer_head as SH
+    c = SWIN_SEGFORMER_CFG
+    enc = ref.SwinTransformerNNFormer(pretrain_img_size=c["vol"], patch_size=(2, 2, 2), in_chans=1, embed_dim=c["embed_dim"],
+                                      depths=c["depths"], num_heads=c["num_heads"], window_size=c["window_size"],
+                                      qkv_bias=True, drop_path_rate=0.0)
+    net = SH.SegFormerHead(encoder=enc, in_channels=[c["embed_dim"] * 2 ** i for i in range(5)], num_classes=c["classes"],
+                           dropout_ratio=0.0, embedding_dim=c["embedding_dim"])
+    det_fill_(net, "swsf.")
+    net.train()
+    x = det_tensor("swsf_x", (2, 1) + c["vol"])
+    y = net((x, None, None))
+    (y * det_tensor("swsf_r", tuple(y.shape))).sum().backward()
+    P = dict(net.named_parameters())
+    out = dict(logits=y, **{"g:" + k: probe(P[k].grad) for k in c["probes"]})
+    for i in range(4):
+        bn = getattr(net, f"linear_fuse_{i}").bn
+        out[f"rm{i}"], out[f"rv{i}"] = bn.running_mean, bn.running_var
+    net.eval()
+    with torch.no_grad():
+        out["logits_eval"] = net((x, None, None))
+    _save("swin_segformer_ref.npz", **out)
+
+
+def gen_param_order(ref):
+    """ordered (name, shape) lists of `named_parameters()` of the reference's own model classes: what torch.optim.AdamW's
+    state dict indexes by position (the reference's checkpoints, utils/misc.py:268-283).  optim.FlatAdamW maps such a
+    state onto this build's modules by position, so their parameter ORDER must be the reference's."""
+    import json
+    import models.backbones.segformer_backbone as SB
+    import models.backbones.swindepth as SD
+    import models.backbones.swinception as SI
+    import models.segmentors.segformer_head as SH
+    import models.segmentors.segformer_head_official as SHO
+    import models.segmentors.unetr as UN
+    kw = dict(pretrain_img_size=(32, 32, 32), patch_size=(2, 2, 2), in_chans=1, embed_dim=16, depths=[2, 2], num_heads=[1, 2],
+              window_size=[4, 4])
+    fams = {"swin_nnformer": ref.SwinTransformerNNFormer(**kw),
+            "swindepth": SD.SwinDepth(**kw, use_learned_cls_vectors=False, out_indices=(0, 1)),
+            "swinception": SI.SwInception(**kw, use_learned_cls_vectors=False, out_indices=(0, 1))}
+    enc = SB.MixVisionTransformer(img_size=64, patch_size=16, in_chans=1, embed_dim=32, depths=[1, 1, 1, 1],
+                                  num_heads=[1, 2, 4, 8], sr_ratios=[8, 4, 2, 1], qkv_bias=True)
+    fams["segformer3d"] = SHO.SegFormerHeadOfficial(encoder=enc, in_channels=[32, 64, 128, 256], num_classes=3, embedding_dim=64)
+    c = SWIN_SEGFORMER_CFG
+    enc = ref.SwinTransformerNNFormer(pretrain_img_size=c["vol"], patch_size=(2, 2, 2), in_chans=1, embed_dim=c["embed_dim"],
+                                      depths=c["depths"], num_heads=c["num_heads"], window_size=c["window_size"], qkv_bias=True)
+    fams["swin_segformer"] = SH.SegFormerHead(encoder=enc, in_channels=[c["embed_dim"] * 2 ** i for i in range(5)],
+                                              num_classes=c["classes"], embedding_dim=c["embedding_dim"])
+    fams["unetrc"] = UN.UNETRC(ToyTokenEncoder(1, 48, (32, 32, 32), (16, 16, 16)), in_chans=1, output_dim=2)
+    out = {k: [[n, list(p.shape)] for n, p in m.named_parameters()] for k, m in fams.items()}
+    path = os.path.join(REPO, "tests", "golden", "param_order.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh)
+    print("wrote", path, {k: len(v) for k, v in out.items()})
+
+
 def gen_lr_and_misc():
     from models.optimizers.lr_scheduler import LinearWarmupCosineAnnealingLR
     import utils.misc as misc
@@ -445,24 +505,27 @@ def gen_swin_official():
 
 
 def main():
+    """`python oracle/gen_golden.py` rewrites every fixture; `python oracle/gen_golden.py swin_segformer param_order`
+    only the named ones (function names without the gen_ prefix)."""
     if not os.path.isdir(REF):
         raise SystemExit("needs /root/reference (build container only)")
     torch.set_num_threads(8)
     _install_import_shims()
     import models.backbones.swin_nnformer as ref
-    gen_window_attention(ref)
-    gen_block(ref)
-    gen_basic_layer_mask(ref)
-    gen_encoder(ref)
-    gen_swindepth()
-    gen_swinception()
-    gen_segformer3d()
-    gen_lr_and_misc()
-    gen_unetr_conv_blocks()
-    gen_unetrc()
-    gen_sliding_window_loop()
-    gen_layers()
-    gen_swin_official()
+    only = set(sys.argv[1:])
+    jobs = [("window_attention", lambda: gen_window_attention(ref)), ("block", lambda: gen_block(ref)),
+            ("basic_layer_mask", lambda: gen_basic_layer_mask(ref)), ("encoder", lambda: gen_encoder(ref)),
+            ("swindepth", gen_swindepth), ("swinception", gen_swinception), ("segformer3d", gen_segformer3d),
+            ("swin_segformer", lambda: gen_swin_segformer(ref)), ("param_order", lambda: gen_param_order(ref)),
+            ("lr_and_misc", gen_lr_and_misc), ("unetr_conv_blocks", gen_unetr_conv_blocks), ("unetrc", gen_unetrc),
+            ("sliding_window_loop", gen_sliding_window_loop), ("layers", gen_layers),
+            ("swin_official", gen_swin_official)]      # swin_official last: it rebinds the MONAI placeholders
+    unknown = only - {n for n, _ in jobs}
+    if unknown:
+        raise SystemExit(f"unknown fixture(s) {sorted(unknown)}")
+    for name, fn in jobs:
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":

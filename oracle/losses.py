@@ -7,7 +7,7 @@ smooth_nr, smooth_dr)`` as constructed at
 reduction="none", get_not_nans=True)`` + ``AsDiscrete`` as used at
 ``/root/reference/engine/train.py:29-31,89-111``.
 MONAI itself is absent -> parity unpinned vs MONAI; known-answer tests in
-``tests/test_oracle_known_answers.py``.
+``tests/test_host_logic.py`` (closed forms of SURVEY.md 8(c)).
 """
 from __future__ import annotations
 

@@ -150,3 +150,31 @@ class SegFormerHeadOfficial(nn.Module):
                          vol_of(self.linear_c1, c1)], dim=1)
         x = self.linear_pred(self.dropout(self.linear_fuse(cat)))
         return F.interpolate(x, size=vol.shape[2:], mode="trilinear", align_corners=False)
+
+
+class SegFormerHead(nn.Module):
+    """/root/reference/models/segmentors/segformer_head.py:40-121 (the 'SwinSegFormer' head): coarse-to-fine fusion of FIVE
+    feature maps, the fused map upsampled to the input size before Dropout3d and the prediction conv"""
+
+    def __init__(self, encoder, in_channels, num_classes, dropout_ratio=0.1, embedding_dim=512):
+        super().__init__()
+        self.encoder = encoder
+        c0, c1, c2, c3, c4 = in_channels
+        self.linear_c4, self.linear_c3 = _MLP(c4, embedding_dim), _MLP(c3, embedding_dim)
+        self.linear_c2, self.linear_c1 = _MLP(c2, embedding_dim), _MLP(c1, embedding_dim)
+        self.linear_c0 = _MLP(c0, embedding_dim)
+        for i in range(4):
+            self.add_module(f"linear_fuse_{i}", _BasicConv3d(embedding_dim * 2, embedding_dim))
+        self.dropout = nn.Dropout3d(dropout_ratio)
+        self.linear_pred = nn.Conv3d(embedding_dim, num_classes, kernel_size=1)
+
+    def forward(self, inputs):
+        vol = inputs[0] if isinstance(inputs, (tuple, list)) else inputs
+        c = self.encoder(inputs)
+        n = c[0].shape[0]
+        vol_of = lambda m, t: m(t).permute(0, 2, 1).reshape(n, -1, *t.shape[2:])
+        up = lambda t, size: F.interpolate(t, size=size, mode="trilinear", align_corners=False)
+        x = vol_of(self.linear_c4, c[4])
+        for i in (3, 2, 1, 0):
+            x = getattr(self, f"linear_fuse_{i}")(torch.cat([up(x, c[i].shape[2:]), vol_of(getattr(self, f"linear_c{i}"), c[i])], 1))
+        return self.linear_pred(self.dropout(up(x, vol.shape[2:])))

@@ -65,6 +65,12 @@ def main(cfg):
     loader_val = SyntheticLoader(1, 1, vval, cfg.in_chans, cfg.output_dim, seed + 7, with_crop_info=False)
 
     model = build_model(cfg).to(device)
+    if cfg.distributed:
+        # /root/reference/run_training.py:83: every BatchNorm uses the statistics of the global batch under data
+        # parallelism (SwinDepth / SwInception / SegFormer3D carry BatchNorms; the InstanceNorm models have none)
+        n_bn = parallel.convert_sync_batchnorm(model)
+        if n_bn and misc.is_main_process():
+            print(f"SyncBatchNorm: {n_bn} BatchNorm holder(s) switched to cross-rank statistics")
     print("parameters:", misc.count_parameters(model))
     groups = add_weight_decay(model, cfg.weight_decay)
     optimizer = FlatAdamW(groups, lr=cfg.lr, betas=(0.9, 0.95), eps=1e-6)

@@ -93,3 +93,13 @@ def probe(t, n=4096):
 
 # the SegFormer3D fixture (tests/golden/segformer3d_ref.npz): MixVisionTransformer + SegFormerHeadOfficial, qkv_bias on
 SEGFORMER_CFG = dict(vol=(64, 64, 64), embed_dim=32, depths=[2, 1, 1, 1], num_heads=[1, 2, 4, 8], classes=3, embedding_dim=64)
+
+# the SwinSegFormer fixture (tests/golden/swin_segformer_ref.npz): SwinTransformerNNFormer + SegFormerHead
+# (/root/reference/models/model_builder.py:173-189), five feature maps 16^3 ... 1^3 at 32^3 / patch 2
+SWIN_SEGFORMER_CFG = dict(vol=(32, 32, 32), embed_dim=16, depths=[2, 1, 1, 1], num_heads=[1, 2, 4, 8], window_size=[4, 4, 4, 2],
+                          classes=3, embedding_dim=32,
+                          probes=["encoder.patch_embed.proj.weight", "encoder.layers.0.blocks.1.attn.qkv.weight",
+                                  "encoder.layers.3.blocks.0.mlp.fc2.weight", "encoder.norm3.weight", "linear_c4.proj.weight",
+                                  "linear_c0.proj.weight", "linear_c2.proj.weight", "linear_fuse_3.conv.weight",
+                                  "linear_fuse_3.bn.weight", "linear_fuse_0.conv.weight", "linear_fuse_0.bn.bias",
+                                  "linear_fuse_2.bn.weight", "linear_pred.weight", "linear_pred.bias"])

@@ -57,6 +57,100 @@ def _grad_rel_l2(net, ref, skip_bias_before_norm=True):
     return (num / den) ** 0.5, worst
 
 
+def _soft_dice_term(logits, y, smooth=1e-5):
+    """the Dice half of DiceCELoss(to_onehot_y, softmax, squared_pred) from fp32 CPU logits: what north_star's "within 1e-3
+    Dice" is checked on (the product's bf16 logits vs the fp32 oracle's, same labels)"""
+    p = torch.softmax(logits.double(), 1)
+    t = torch.nn.functional.one_hot(y[:, 0].long(), logits.shape[1]).permute(0, 4, 1, 2, 3).double()
+    inter = (p * t).flatten(2).sum(-1)
+    den = (p * p).flatten(2).sum(-1) + (t * t).flatten(2).sum(-1)
+    return float((1.0 - (2.0 * inter + smooth) / (den + smooth)).mean())
+
+
+def _hard_dice(logits, y):
+    """per-class Dice of the arg-max map against the labels (DiceMetric, include_background)"""
+    a, t = logits.argmax(1), y[:, 0].long()
+    return [2.0 * float(((a == c) & (t == c)).sum()) / max(float((a == c).sum() + (t == c).sum()), 1.0)
+            for c in range(logits.shape[1])]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unet_base_96_vs_oracle(dtype):
+    """BASELINE configs[1] ITSELF -- UNet base 1->3, 96^3, B = 2, DiceCE -- against oracle.blocks.BasicUNet +
+    oracle.losses.dice_ce_loss on the CPU (reference call site: /root/reference/engine/train.py:60-62).  fp32 compute
+    mode is the parity gate (logits rtol 1e-4, loss 1e-4, whole-net gradient rel-L2 < 1e-3); bf16 (the benchmarked dtype)
+    is gated at about twice its measured drift, and on the soft-Dice term (< 1e-3, north_star)."""
+    from medicalsemseg_amd.losses import DiceCELoss
+    from medicalsemseg_amd.models.unet import UNET_FEATURES, UNet
+    from oracle.blocks import BasicUNet
+    from oracle.losses import dice_ce_loss
+    S, B = 96, 2
+    torch.manual_seed(0)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = BasicUNet(1, 3, UNET_FEATURES["UNet"])
+    net = UNet(1, 3, UNET_FEATURES["UNet"], compute_dtype=dtype)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, 1, S, S, S, generator=g)
+    y = _blobs(B, S, 3, 14)
+    out_ref = ref(x)
+    loss_ref = dice_ce_loss(out_ref, y)
+    loss_ref.backward()
+    out = net((x.to(DEV), None, None))
+    loss = DiceCELoss()(out, y.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    o = out.detach().float().cpu()
+    tot, worst = _grad_rel_l2(net, ref)
+    scale = float(out_ref.abs().max())
+    drift = float((o - out_ref.detach()).abs().max()) / scale
+    sd, sd_ref = _soft_dice_term(o, y), _soft_dice_term(out_ref.detach(), y)
+    hd, hd_ref = _hard_dice(o, y), _hard_dice(out_ref.detach(), y)
+    dl = abs(float(loss.detach()) - float(loss_ref.detach()))
+    print(f"[{dtype}] UNet base 96^3 B=2 vs CPU oracle: logits err/scale {drift:.3e}, |loss diff| {dl:.3e}, soft-Dice term "
+          f"{sd:.6f} vs {sd_ref:.6f} (diff {abs(sd - sd_ref):.2e}), hard Dice {['%.4f' % v for v in hd]} vs "
+          f"{['%.4f' % v for v in hd_ref]}, grad rel-L2 {tot:.3e}, worst {worst}")
+    assert abs(sd - sd_ref) < 1e-3
+    if dtype == torch.float32:
+        np.testing.assert_allclose(o.numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+        assert dl < 1e-4 and tot < 1e-3
+        assert max(abs(a - b) for a, b in zip(hd, hd_ref)) < 1e-3
+    else:
+        # measured on MI355X: drift 1.2e-2 of scale, gradients 9.6e-3 -> gates at about twice that
+        assert drift < 2.5e-2 and tot < 2e-2 and dl < 5e-3
+
+
+def test_unet_small_config0_64_vs_oracle():
+    """BASELINE configs[0] at its stated size: UNet-small 1->2, 64^3 random volumes, batch 2, against the CPU oracle (fp32
+    compute mode: logits rtol 1e-4, loss 1e-4, gradient rel-L2 < 1e-3)"""
+    from medicalsemseg_amd.losses import DiceCELoss
+    from medicalsemseg_amd.models.unet import UNET_FEATURES, UNet
+    from oracle.blocks import BasicUNet
+    from oracle.losses import dice_ce_loss
+    S, B = 64, 2
+    torch.manual_seed(0)
+    ref = BasicUNet(1, 2, UNET_FEATURES["UNetSmall"])
+    net = UNet(1, 2, UNET_FEATURES["UNetSmall"], compute_dtype=torch.float32)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(13)                       # utils/arguments.py:301 default seed
+    x = torch.randn(B, 1, S, S, S, generator=g)
+    y = torch.randint(0, 2, (B, 1, S, S, S), generator=g).float()
+    out_ref = ref(x)
+    loss_ref = dice_ce_loss(out_ref, y)
+    loss_ref.backward()
+    out = net((x.to(DEV), None, None))
+    loss = DiceCELoss()(out, y.to(DEV))
+    loss.backward()
+    o = out.detach().float().cpu()
+    np.testing.assert_allclose(o.numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    tot, worst = _grad_rel_l2(net, ref)
+    print(f"UNet-small 64^3 B=2 fp32: |loss diff| {abs(float(loss) - float(loss_ref)):.2e}, grad rel-L2 {tot:.3e}, worst {worst}")
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4 and tot < 1e-3
+    assert abs(_soft_dice_term(o, y) - _soft_dice_term(out_ref.detach(), y)) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_unet_base_48_vs_oracle(dtype):
     """BASELINE configs[1]'s network (UNet base 1->3, B = 2) at 48^3: 864 tiles -> the ping-pong kernels are selected"""
@@ -107,7 +201,12 @@ def test_unet_base_48_vs_oracle(dtype):
         drift = float((o - out_ref.detach()).abs().max()) / float(out_ref.abs().max())
         tot, worst = _grad_rel_l2(net, ref)
         print(f"[bf16] UNet base 48^3 logits drift vs fp32 oracle {drift:.3e}, grad rel-L2 {tot:.3e}, worst {worst}")
-        assert drift < 0.06 and abs(float(loss) - float(loss_ref)) < 2e-2 and tot < 0.12
+        sd, sd_ref = _soft_dice_term(o, y), _soft_dice_term(out_ref.detach(), y)
+        print(f"[bf16] UNet base 48^3 soft-Dice term {sd:.6f} vs fp32 oracle {sd_ref:.6f}, |loss diff| "
+              f"{abs(float(loss) - float(loss_ref)):.2e}")
+        # gates at about twice the measured values (drift 1.2e-2, gradients 9.6e-3)
+        assert drift < 2.5e-2 and abs(float(loss) - float(loss_ref)) < 5e-3 and tot < 2e-2
+        assert abs(sd - sd_ref) < 1e-3
         # tight forward check: the oracle on bf16-rounded weights with bf16-rounded stored tensors
         ref16 = BasicUNet(1, 3, UNET_FEATURES["UNet"])
         ref16.load_state_dict({k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in ref.state_dict().items()})
@@ -118,7 +217,7 @@ def test_unet_base_48_vs_oracle(dtype):
             h.remove()
         err = float((o - o16).abs().max()) / float(o16.abs().max())
         print(f"[bf16] UNet base 48^3 logits vs bf16-storage oracle {err:.3e}")
-        assert err < 3e-2
+        assert err < 1.5e-2                       # measured 7.2e-3
         dice_ref = out_ref.argmax(1)
         a = o.argmax(1)
         for c in range(3):
@@ -148,12 +247,12 @@ def test_unet_base_96_full_size_step_properties():
 
     net32, l32, g32 = grads(torch.float32)
     net, l16, g16 = grads(torch.bfloat16)
-    assert np.isfinite(l16) and abs(l16 - l32) < 2e-2
+    assert np.isfinite(l16) and abs(l16 - l32) < 5e-3
     num = sum(float(((g16[n] - g32[n]) ** 2).sum()) for n in g32 if not (n.endswith("conv.bias") and "final" not in n))
     den = sum(float((g32[n] ** 2).sum()) for n in g32 if not (n.endswith("conv.bias") and "final" not in n))
     rel = (num / den) ** 0.5
     print(f"96^3 B=2: bf16 vs exact-fp32 HIP gradients rel-L2 {rel:.3e}, loss {l16:.5f} vs {l32:.5f}")
-    assert rel < 0.12
+    assert rel < 1e-2                             # measured 3.7e-3
     del net32, g32
     # eager step vs hipGraph replay of the same step (forward + loss + backward + AdamW), three steps each
     def run(graphed):
@@ -230,8 +329,12 @@ def test_swin_unetr_48_config_vs_oracle(dtype):
         np.testing.assert_allclose(o.numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=2e-4 * max(scale, 1.0))
         assert abs(float(loss) - float(loss_ref)) < 1e-4
         assert tot < 2e-3
-    else:
-        assert err < 0.08 and abs(float(loss) - float(loss_ref)) < 3e-2 and tot < 0.15
+    sd, sd_ref = _soft_dice_term(o, y), _soft_dice_term(out_ref.detach(), y)
+    print(f"[{dtype}] Swin-UNETR-48 96^3 soft-Dice term {sd:.6f} vs oracle {sd_ref:.6f}")
+    assert abs(sd - sd_ref) < 1e-3
+    if dtype == torch.bfloat16:
+        # measured: logits 8.0e-3 of scale, gradients 2.5e-3 -> gates at about twice that
+        assert err < 1.6e-2 and abs(float(loss) - float(loss_ref)) < 5e-3 and tot < 6e-3
 
 
 def _unet_pair(dtype=torch.float32):
@@ -280,17 +383,22 @@ def test_sliding_window_512_properties():
         out = U.sliding_window_inference(x, aff, (R,) * 3, 8, net, overlap=0.5, mode="gaussian")
     assert out.shape == (1, 3, V, V, V)
     assert bool(torch.isfinite(out).all())           # cnt > 0 everywhere (a zero count would give inf / nan)
-    # sub-cube [200:232)^3: recompute every window that covers any part of it, one window per forward, torch blend
+    # sub-cube [200:232)^3: recompute every window that covers any part of it with the CPU ORACLE network (fp32), one
+    # window per forward, torch blend on the CPU with the oracle's importance map (reference: engine/utils.py:120-151)
+    from oracle.sliding_window import compute_importance_map
+    ref, _ = _unet_pair(torch.bfloat16)               # the same seed-0 weights as `net`
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     lo, hi = 200, 232
-    imp = U.importance_map((R,) * 3, "gaussian", 0.125, DEV)
-    acc = torch.zeros(3, hi - lo, hi - lo, hi - lo, device=DEV)
-    cnt = torch.zeros(hi - lo, hi - lo, hi - lo, device=DEV)
+    imp = compute_importance_map((R,) * 3, "gaussian", 0.125).float()
+    acc = torch.zeros(3, hi - lo, hi - lo, hi - lo)
+    cnt = torch.zeros(hi - lo, hi - lo, hi - lo)
+    xc = x.cpu()
     n = 0
     with torch.no_grad():
         for st in starts:
             if all(st[d] < hi and st[d] + R > lo for d in range(3)):
-                win = x[:, :, st[0]:st[0] + R, st[1]:st[1] + R, st[2]:st[2] + R].contiguous()
-                seg = net((win, None, None)).float()[0]
+                win = xc[:, :, st[0]:st[0] + R, st[1]:st[1] + R, st[2]:st[2] + R].contiguous()
+                seg = ref(win).float()[0]
                 sl_v = [slice(max(lo, st[d]) - lo, min(hi, st[d] + R) - lo) for d in range(3)]
                 sl_w = [slice(max(lo, st[d]) - st[d], min(hi, st[d] + R) - st[d]) for d in range(3)]
                 acc[(slice(None), *sl_v)] += imp[tuple(sl_w)] * seg[(slice(None), *sl_w)]
@@ -298,11 +406,13 @@ def test_sliding_window_512_properties():
                 n += 1
     assert n >= 8
     want = acc / cnt
-    got = out[0, :, lo:hi, lo:hi, lo:hi]
+    got = out[0, :, lo:hi, lo:hi, lo:hi].float().cpu()
     err = float((got - want).abs().max()) / float(want.abs().max())
-    print(f"512^3 sub-cube: {n} windows recomputed, max err / scale {err:.3e}")
-    # batch-of-8 vs batch-of-1 forwards differ only in the order of the fp32 statistics partial sums
-    assert err < 2e-2
+    agree = float((got.argmax(0) == want.argmax(0)).float().mean())
+    print(f"512^3 sub-cube: {n} windows recomputed by the fp32 CPU oracle, bf16 product max err / scale {err:.3e}, "
+          f"arg-max agreement {agree:.4f}")
+    # bf16 network against the fp32 oracle: the whole-net drift is 1.2e-2 of scale (test_unet_base_*), gate at twice that
+    assert err < 2.5e-2 and agree > 0.97
 
 
 def test_sliding_window_sharded_two_ranks_equals_single_rank():

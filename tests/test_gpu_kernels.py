@@ -368,11 +368,13 @@ def test_unet_small_fwd_bwd(dtype):
         gtol = 5e-3
     else:
         err = float((out.detach().cpu() - out_ref.detach()).abs().max()) / float(out_ref.abs().max())
-        assert err < 0.06, f"bf16 logits drift {err}"
-        assert abs(float(loss) - float(loss_ref)) < 2e-2
+        print(f"[bf16] UNet-small logits drift {err:.3e}, |loss diff| {abs(float(loss) - float(loss_ref)):.2e}")
+        assert err < 3e-2, f"bf16 logits drift {err}"
+        assert abs(float(loss) - float(loss_ref)) < 1e-2
         gtol = 0.3   # bf16 storage of activations AND gradients through 18 conv layers; fp32 path is the parity gate
     pr = dict(ref.named_parameters())
     num = den = 0.0
+    worst_p = 0.0
     for name, p in net.named_parameters():
         assert p.grad is not None, name
         if name.endswith("conv.bias") and "final" not in name:
@@ -384,10 +386,11 @@ def test_unet_small_fwd_bwd(dtype):
             err = float((p.grad.cpu() - gr).abs().max()) / (float(gr.abs().max()) + 1e-8)
             assert err < gtol, f"{name}: grad rel err {err:.3e}"
         else:
-            assert (d2 / (r2 + 1e-20)) ** 0.5 < 0.5, f"{name}: bf16 grad rel L2 err {(d2 / r2) ** 0.5:.3e}"
+            worst_p = max(worst_p, (d2 / (r2 + 1e-20)) ** 0.5)
+            assert (d2 / (r2 + 1e-20)) ** 0.5 < 0.25, f"{name}: bf16 grad rel L2 err {(d2 / r2) ** 0.5:.3e}"
     tot = (num / den) ** 0.5
-    print(f"[{dtype}] whole-net grad rel L2 err {tot:.3e}")
-    assert tot < (1e-3 if dtype == torch.float32 else 0.12)
+    print(f"[{dtype}] whole-net grad rel L2 err {tot:.3e}, worst single parameter {worst_p:.3e}")
+    assert tot < (1e-3 if dtype == torch.float32 else 4e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -1021,3 +1024,48 @@ def test_dropout3d_with_given_mask():
     y.sum().backward()
     assert torch.allclose(x.grad, (mask / 0.75).to(dev).view(3, 1, 1, 1, 16).expand_as(x), rtol=1e-6)
     assert ops.dropout3d(x, 0.25, False) is x
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_avg_pool3_no_systematic_bias(dtype):
+    """AvgPool3d(3, 1, 1) of the SwInception pooling branch (/root/reference/models/backbones/swinception.py:113-116): unit
+    taps and the fp32 sum scaled by 1/27 -- a bf16 tap of 1/27 (0.0371094) would put +0.195 % on every output, forward and
+    backward.  Positive inputs make a scale error visible as a mean relative error."""
+    from medicalsemseg_amd import ops
+    DEV = _dev()
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(2, 10, 12, 14, 16, generator=g) + 0.5).to(DEV).to(dtype).requires_grad_(True)
+    y = ops.avg_pool3(x)
+    ref = torch.nn.functional.avg_pool3d(x.detach().float().permute(0, 4, 1, 2, 3), 3, 1, 1).permute(0, 2, 3, 4, 1)
+    rel = (y.detach().float() - ref) / ref
+    r = torch.rand(y.shape, generator=g).to(DEV) + 0.5
+    y.backward(r.to(dtype))
+    gref = torch.nn.functional.avg_pool3d(r.to(dtype).float().permute(0, 4, 1, 2, 3), 3, 1, 1).permute(0, 2, 3, 4, 1)
+    grel = (x.grad.float() - gref) / gref
+    tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8
+    print(f"[{dtype}] avg_pool3 mean rel err fwd {float(rel.mean()):.2e} bwd {float(grel.mean()):.2e}, max {float(rel.abs().max()):.2e}")
+    assert float(rel.abs().max()) < tol and float(grel.abs().max()) < tol
+    assert abs(float(rel.mean())) < 2e-4 and abs(float(grel.mean())) < 2e-4      # the bf16-tap form sat at +1.95e-3
+
+
+def test_eval_batchnorm_large_mean_small_variance():
+    """eval-mode BatchNorm with running_mean^2 >> running_var (mean 10, var 1e-2): the folded scale / shift form keeps
+    full fp32 accuracy where sums rebuilt from the running statistics lose three digits (E[x^2] - mean^2)"""
+    from medicalsemseg_amd import ops
+    DEV = _dev()
+    C = 16
+    bn = torch.nn.BatchNorm3d(C, eps=1e-5).to(DEV).eval()
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        bn.running_mean.copy_(10.0 + torch.rand(C, generator=g).to(DEV))
+        bn.running_var.copy_(1e-2 * (1 + torch.rand(C, generator=g).to(DEV)))
+        bn.weight.copy_(1 + 0.1 * torch.randn(C, generator=g).to(DEV))
+        bn.bias.copy_(0.1 * torch.randn(C, generator=g).to(DEV))
+    x = (10.5 + 0.1 * torch.randn(2, 6, 6, 6, C, generator=g)).to(DEV)
+    with torch.no_grad():
+        y = ops.batch_norm(x, bn, None)
+        xd = x.double()
+        want = (xd - bn.running_mean.double()) * torch.rsqrt(bn.running_var.double() + bn.eps) * bn.weight.double() + bn.bias.double()
+    err = float((y.double() - want).abs().max()) / float(want.abs().max())
+    print(f"eval BatchNorm (mean 10, var 1e-2): max err / scale {err:.2e}")
+    assert err < 5e-6

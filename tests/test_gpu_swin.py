@@ -9,6 +9,10 @@ import torch
 from tests.golden_util import det_fill_, det_tensor
 
 pytestmark = pytest.mark.gpu
+
+# bf16 whole-net gates (logits err / scale, |loss difference|, whole-net gradient rel-L2) vs the fp32 CPU oracle: about twice
+# the values measured on MI355X (printed by the tests), so that a 2-3x regression of the bf16 path fails
+BF16_GATES = {"swin32": (3e-2, 1e-2, 5e-2), "official64": (2e-2, 1e-2, 4e-2)}
 DEV = "cuda:0"
 
 
@@ -163,8 +167,10 @@ def test_swin_unetr_vs_oracle(dtype):
         np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=2e-4)
         assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4
     else:
-        assert _rel(out, out_ref.detach().numpy()) < 0.08
-        assert abs(float(loss.detach()) - float(loss_ref.detach())) < 3e-2
+        print(f"[bf16] Swin-UNETR 32^3: logits err/scale {_rel(out, out_ref.detach().numpy()):.3e}, |loss diff| "
+              f"{abs(float(loss.detach()) - float(loss_ref.detach())):.2e}")
+        assert _rel(out, out_ref.detach().numpy()) < BF16_GATES["swin32"][0]
+        assert abs(float(loss.detach()) - float(loss_ref.detach())) < BF16_GATES["swin32"][1]
     pr = dict(ref.named_parameters())
     num = den = 0.0
     for name, p in net.named_parameters():
@@ -173,7 +179,8 @@ def test_swin_unetr_vs_oracle(dtype):
         num += float(((p.grad.cpu() - gr) ** 2).sum())
         den += float((gr ** 2).sum())
     tot = (num / den) ** 0.5
-    assert tot < (2e-3 if dtype == torch.float32 else 0.15), f"whole-net grad rel L2 err {tot:.3e}"
+    print(f"[{dtype}] Swin-UNETR 32^3 whole-net grad rel-L2 {tot:.3e}")
+    assert tot < (2e-3 if dtype == torch.float32 else BF16_GATES["swin32"][2]), f"whole-net grad rel L2 err {tot:.3e}"
 
 
 def test_swin_official_encoder_vs_reference_golden(golden_dir):
@@ -250,7 +257,10 @@ def test_swin_official_net_vs_reference_golden_and_oracle(golden_dir, dtype):
     if dtype == torch.float32:
         assert err < 2e-4 and abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4 and tot < 2e-3
     else:
-        assert err < 0.08 and abs(float(loss.detach()) - float(loss_ref.detach())) < 3e-2 and tot < 0.15
+        print(f"[bf16] official Swin-UNETR 64^3 |loss diff| {abs(float(loss.detach()) - float(loss_ref.detach())):.2e}")
+        # measured 9.1e-3 / 1.9e-2: gates at about twice that
+        assert err < BF16_GATES["official64"][0] and abs(float(loss.detach()) - float(loss_ref.detach())) < BF16_GATES["official64"][1] \
+            and tot < BF16_GATES["official64"][2]
 
 
 @pytest.mark.parametrize("R,ws,heads,C,shift,bws", [(12, 7, 3, 48, 3, 7), (14, 7, 4, 64, 0, 7), (9, 7, 3, 48, 3, 7),
@@ -464,3 +474,45 @@ def test_segformer3d_vs_reference_golden(golden_dir, dtype):
     net.eval()
     with torch.no_grad():
         assert _rel(sub(net((x, None, None))), g["logits_eval_s2"]) < tf
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swin_segformer_vs_reference_golden(golden_dir, dtype):
+    """'SwinSegFormer' (SwinTransformerNNFormer + the progressive-fusion SegFormerHead; /root/reference/models/
+    model_builder.py:173-189, models/segmentors/segformer_head.py:40-121) against the reference's own classes
+    (tests/golden/swin_segformer_ref.npz): training-mode logits, gradient probes through encoder, every fusion level and the
+    prediction conv, the four BatchNorms' running statistics, eval-mode logits.  The product applies dropout + prediction
+    conv before the final upsampling (they commute with it): fp32 must still meet rtol 1e-4-level agreement."""
+    from medicalsemseg_amd.models.segformer3d import SegFormerHead
+    from medicalsemseg_amd.models.swin_unetr import SwinTransformerNNFormer
+    from tests.golden_util import SWIN_SEGFORMER_CFG as c, probe
+    g = _load(golden_dir, "swin_segformer_ref.npz")
+    enc = SwinTransformerNNFormer(c["vol"], (2, 2, 2), 1, c["embed_dim"], tuple(c["depths"]), tuple(c["num_heads"]),
+                                  tuple(c["window_size"]), drop_path_rate=0.0, compute_dtype=dtype)
+    net = SegFormerHead(enc, [c["embed_dim"] * 2 ** i for i in range(5)], c["classes"], 0.0, c["embedding_dim"],
+                        compute_dtype=dtype)
+    det_fill_(net, "swsf.")
+    net = net.to(DEV).train()
+    x = det_tensor("swsf_x", (2, 1) + c["vol"]).to(DEV)
+    y = net((x, None, None))
+    e_log = _rel(y, g["logits"])
+    (y.float() * det_tensor("swsf_r", tuple(y.shape)).to(DEV)).sum().backward()
+    P = dict(net.named_parameters())
+    eg = {}
+    for k in c["probes"]:
+        w = g["g:" + k]
+        got = probe(P[k].grad).float().cpu().numpy()
+        eg[k] = float(np.linalg.norm(got - w) / np.linalg.norm(w))
+    print(f"[{dtype}] SwinSegFormer 32^3 logits err/scale {e_log:.2e}; gradient probe rel-L2:", {k: f"{v:.2e}" for k, v in eg.items()})
+    tf, tg = (2e-4, 5e-3) if dtype == torch.float32 else (5e-2, 1.5e-1)
+    assert e_log < tf and max(eg.values()) < tg, (e_log, eg)
+    if dtype == torch.float32:
+        for i in range(4):
+            bn = getattr(net, f"linear_fuse_{i}").bn
+            assert np.allclose(bn.running_mean.cpu().numpy(), g[f"rm{i}"], atol=1e-4), i
+            assert np.allclose(bn.running_var.cpu().numpy(), g[f"rv{i}"], atol=1e-4), i
+    net.eval()
+    with torch.no_grad():
+        e_eval = _rel(net((x, None, None)), g["logits_eval"])
+    print(f"[{dtype}] SwinSegFormer eval logits err/scale {e_eval:.2e}")
+    assert e_eval < tf

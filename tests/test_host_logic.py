@@ -123,10 +123,68 @@ def test_build_model_surface():
     sw = build_model(get_args("--model nnFormerUNETR --patch_size 2 --window_size 6 6 6 3 --qkv_bias --output_dim 3".split()))
     n_enc = sum(p.numel() for p in sw.encoder.parameters())
     assert n_enc == 15362430, n_enc   # the reference encoder's parameter count
+    sf = build_model(get_args("--model SwinSegFormer --patch_size 2 --window_size 6 6 6 3 --qkv_bias --output_dim 3".split()))
+    assert sum(p.numel() for p in sf.encoder.parameters()) == 15362430 and sf.linear_fuse_0.conv.weight.shape == (512, 1024, 1, 1, 1)
     with pytest.raises(NotImplementedError):
         build_model(get_args("--model FocalNetUNETR".split()))
     with pytest.raises(ValueError):
         build_model(get_args([]))   # the reference's default 'UNETR_Official' matches no branch either
+
+
+def test_parameter_order_matches_reference_classes(golden_dir):
+    """optim.FlatAdamW maps a torch.optim.AdamW state (the reference's checkpoints) onto the flat moments BY POSITION, so
+    `named_parameters()` of every model family must enumerate in the reference's order (tests/golden/param_order.json:
+    ordered names + shapes taken from the reference's own classes by oracle/gen_golden.py).  SwInception computes on
+    zero-padded channel counts: its names must match, its shapes are the padded ones (state-dict hooks translate)."""
+    import json
+    from medicalsemseg_amd.models import segformer3d as PS, swin_unetr as P, unetrc as PC
+    from medicalsemseg_amd.optim import add_weight_decay
+    from tests.golden_util import SWIN_SEGFORMER_CFG as c, ToyTokenEncoder
+    with open(os.path.join(golden_dir, "param_order.json")) as fh:
+        ref = json.load(fh)
+    kw = dict(patch_size=(2, 2, 2), in_chans=1, embed_dim=16, depths=(2, 2), num_heads=(1, 2), window_size=(4, 4))
+    enc = PS.MixVisionTransformer(64, 16, 1, 32, (1, 2, 4, 8), (4, 4, 4, 4), True, 0.0, (1, 1, 1, 1), (8, 4, 2, 1))
+    senc = P.SwinTransformerNNFormer(c["vol"], (2, 2, 2), 1, c["embed_dim"], tuple(c["depths"]), tuple(c["num_heads"]),
+                                     tuple(c["window_size"]))
+    fams = {"swin_nnformer": P.SwinTransformerNNFormer((32,) * 3, **kw), "swindepth": P.SwinDepth((32,) * 3, **kw),
+            "swinception": P.SwInception((32,) * 3, **kw),
+            "segformer3d": PS.SegFormerHeadOfficial(enc, [32, 64, 128, 256], 3, 0.1, 64),
+            "swin_segformer": PS.SegFormerHead(senc, [c["embed_dim"] * 2 ** i for i in range(5)], c["classes"], 0.1, c["embedding_dim"]),
+            "unetrc": PC.UNETRC(ToyTokenEncoder(1, 48, (32, 32, 32), (16, 16, 16)), 1, 2)}
+    for fam, net in fams.items():
+        got = [(n, list(p.shape)) for n, p in net.named_parameters()]
+        want = [(n, s) for n, s in ref[fam]]
+        assert [n for n, _ in got] == [n for n, _ in want], fam
+        if fam != "swinception":
+            assert got == want, fam
+        # the two AdamW groups (timm add_weight_decay: [no_decay, decay]) then enumerate alike as well
+        groups = add_weight_decay(net, 1e-5)
+        names = {id(p): n for n, p in net.named_parameters()}
+        order = [[names[id(p)] for p in g["params"]] for g in groups]
+        wn = [n for n, s in want if len(s) <= 1 or n.endswith(".bias")], [n for n, s in want if not (len(s) <= 1 or n.endswith(".bias"))]
+        assert order[0] == wn[0] and order[1] == wn[1], fam
+
+
+def test_convert_sync_batchnorm_reaches_every_batchnorm_holder():
+    """run_training.py under --distributed: /root/reference/run_training.py:83 converts every BatchNorm"""
+    from medicalsemseg_amd import layers, parallel
+    from medicalsemseg_amd.models import segformer3d as PS, swin_unetr as P, unetrc as PC
+    from medicalsemseg_amd.models.unet import UNet
+    from tests.golden_util import ToyTokenEncoder
+    kw = dict(patch_size=(2, 2, 2), in_chans=1, embed_dim=16, depths=(2, 1), num_heads=(1, 2), window_size=(4, 4))
+    net = P.SwinUNETRCustom(P.SwinDepth((32,) * 3, **kw), 1, 3, (32,) * 3, 16, (2, 2, 2))
+    assert parallel.convert_sync_batchnorm(net) == 3                      # one _DepthMlp per block
+    assert all(m.sync_group is True for m in net.modules() if hasattr(m, "sync_group"))
+    assert parallel.convert_sync_batchnorm(net, None) == 3 and all(m.sync_group is None for m in net.modules() if hasattr(m, "sync_group"))
+    enc = PS.MixVisionTransformer(64, 16, 1, 32, (1, 2, 4, 8), (4, 4, 4, 4), True, 0.0, (1, 1, 1, 1), (8, 4, 2, 1))
+    assert parallel.convert_sync_batchnorm(PS.SegFormerHeadOfficial(enc, [32, 64, 128, 256], 3, 0.1, 64)) == 1
+    u = PC.UNETRC(ToyTokenEncoder(1, 48, (32, 32, 32), (16, 16, 16)), 1, 2)
+    n = parallel.convert_sync_batchnorm(u)
+    bns = [o.op.norm for ops_ in list(u._branch.values()) + list(u._trunk.values()) for o in ops_ if hasattr(o, "op") and hasattr(o.op, "norm")]
+    assert bns and all(isinstance(b, layers.BatchNormAct) and b.group is True for b in bns) and n == 1 + len(bns)
+    u._build_ops()                                                        # what .to(device) triggers: the switch must survive
+    assert all(o.op.norm.group is True for ops_ in u._trunk.values() for o in ops_ if hasattr(o, "op") and hasattr(o.op, "norm"))
+    assert parallel.convert_sync_batchnorm(UNet(1, 2)) == 0               # InstanceNorm: nothing to exchange
 
 
 def test_swin_unetr_state_dict_matches_oracle_layout():

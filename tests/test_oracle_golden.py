@@ -323,3 +323,33 @@ def test_segformer3d_oracle_vs_reference_files(golden_dir):
     net.eval()
     with torch.no_grad():
         assert np.allclose(sub(net((x, None, None))).numpy(), g["logits_eval_s2"], rtol=1e-3, atol=1e-4)
+
+
+def test_swin_segformer_oracle_vs_reference_files(golden_dir):
+    """oracle/segformer.py SegFormerHead around oracle/swin.py's encoder against the reference's own 'SwinSegFormer' wiring
+    (models/model_builder.py:173-189; tests/golden/swin_segformer_ref.npz): training-mode logits, gradient probes, the four
+    BatchNorms' running statistics, eval-mode logits"""
+    from oracle import segformer as OS, swin as O
+    from tests.golden_util import SWIN_SEGFORMER_CFG as c, probe
+    g = _load(golden_dir, "swin_segformer_ref.npz")
+    torch.set_num_threads(8)
+    enc = O.SwinTransformerNNFormer(c["vol"], patch_size=(2, 2, 2), in_chans=1, embed_dim=c["embed_dim"], depths=tuple(c["depths"]),
+                                    num_heads=tuple(c["num_heads"]), window_size=tuple(c["window_size"]))
+    net = OS.SegFormerHead(enc, [c["embed_dim"] * 2 ** i for i in range(5)], c["classes"], 0.0, c["embedding_dim"])
+    det_fill_(net, "swsf.")
+    net.train()
+    x = det_tensor("swsf_x", (2, 1) + c["vol"])
+    y = net((x, None, None))
+    assert np.allclose(y.detach().numpy(), g["logits"], rtol=1e-3, atol=1e-4)
+    (y * det_tensor("swsf_r", tuple(y.shape))).sum().backward()
+    P = dict(net.named_parameters())
+    for k in c["probes"]:
+        want = g["g:" + k]
+        got = probe(P[k].grad).numpy()
+        assert np.abs(got - want).max() <= 2e-3 * max(np.abs(want).max(), 1e-3), k
+    for i in range(4):
+        bn = getattr(net, f"linear_fuse_{i}").bn
+        assert np.allclose(bn.running_mean.numpy(), g[f"rm{i}"], atol=1e-5) and np.allclose(bn.running_var.numpy(), g[f"rv{i}"], atol=1e-5)
+    net.eval()
+    with torch.no_grad():
+        assert np.allclose(net((x, None, None)).numpy(), g["logits_eval"], rtol=1e-3, atol=1e-4)

@@ -11,7 +11,7 @@ cout = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 size = int(sys.argv[4]) if len(sys.argv) > 4 else 96
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 20
 dev = torch.device("cuda:0")
-N = 2
+N = int(os.environ.get("MSSEG_BENCH_N", "2"))
 dt = torch.bfloat16
 x = torch.randn(N, size, size, size, cin, device=dev).to(dt)
 dy = torch.randn(N, size, size, size, cout, device=dev).to(dt)

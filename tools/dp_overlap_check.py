@@ -102,6 +102,49 @@ def run(overlap: bool, graphs: bool, rank: int, dev, kind="unet"):
     return opt.flat_param.clone()
 
 
+def dp_equivalence(rank, dev):
+    """2 ranks x B=2 with GradSync == 1 process x B=4: every rank takes its half of ONE global batch,
+    three AdamW steps in exact-fp32 compute mode; rank 0 then repeats the three steps alone on the whole batch.  DiceCE is
+    a mean over samples (Dice per (n, c), CE per voxel) and InstanceNorm has no cross-sample term, so the averaged rank
+    gradients ARE the whole-batch gradient: parameters must agree to fp32 reduction-order tolerance."""
+    os.environ.pop("MSSEG_NO_GRAD_OVERLAP", None)
+    g = torch.Generator().manual_seed(77)
+    X = torch.randn(4, 1, 32, 32, 32, generator=g).to(dev)
+    Y = torch.randint(0, 2, (4, 1, 32, 32, 32), generator=g).float().to(dev)
+
+    def steps(x, y, sync):
+        torch.manual_seed(0)
+        net = UNet(1, 2, UNET_FEATURES["UNetSmall"], compute_dtype=torch.float32).to(dev)
+        opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=1e-3, betas=(0.9, 0.95), eps=1e-6)
+        crit = DiceCELoss()
+        gs = parallel.GradSync(opt, net) if sync else None
+        for _ in range(3):
+            crit(net((x, None, None)), y).backward()
+            if gs is not None:
+                if gs.overlapped:
+                    gs.start()
+                    net.backward_tail()
+                gs.finish()
+            opt.step()
+            opt.zero_grad()
+        torch.cuda.synchronize()
+        net.defer_backward_tail(False)
+        return opt.flat_param.clone()
+
+    sl = slice(2 * rank, 2 * rank + 2)
+    p_dp = steps(X[sl], Y[sl], True)
+    torch.distributed.barrier()
+    if rank == 0:
+        p_one = steps(X, Y, False)
+        err = float((p_dp - p_one).abs().max())
+        rel = float((p_dp - p_one).norm() / p_one.norm())
+        print(f"DP_EQUIV max |dp - single| = {err:.3e}, rel-L2 {rel:.3e} over {p_one.numel()} parameters", flush=True)
+        # AdamW's first steps move every parameter by ~lr whatever the gradient's size, and a sign flip of a ~0 gradient
+        # entry moves it by 2 lr: the gate is a few lr on single entries and tight in the norm
+        assert err < 4e-3 and rel < 2e-4, (err, rel)
+    torch.distributed.barrier()
+
+
 def main():
     parallel.init_from_env()
     rank = parallel.rank()
@@ -121,6 +164,7 @@ def main():
         other = ref.clone()
         torch.distributed.broadcast(other, src=0)
         assert torch.equal(other, ref)
+    dp_equivalence(rank, dev)
     torch.distributed.barrier()
     if rank == 0:
         print("DP_OVERLAP_OK", flush=True)

@@ -43,9 +43,46 @@ def main():
     assert torch.allclose(gw, whole.weight.grad, rtol=1e-4, atol=1e-3) and torch.allclose(gb, whole.bias.grad, rtol=1e-4, atol=1e-3)
     assert torch.allclose(mine.running_mean, whole.running_mean, atol=1e-6)
     assert torch.allclose(mine.running_var, whole.running_var, atol=1e-6)
+    model_level(rk, dev)
     torch.distributed.barrier()
     if rk == 0:
         print("SYNCBN_CHECK_OK")
+
+
+def model_level(rk, dev):
+    """the hook run_training.py calls under --distributed (`parallel.convert_sync_batchnorm`, the reference's
+    run_training.py:83) on a whole model: SegFormer3D (BatchNorm in the fusion head) with one sample per rank must
+    reproduce the single-process model on both samples -- logits, running statistics, one encoder gradient after the
+    gradient exchange."""
+    from medicalsemseg_amd.models.segformer3d import MixVisionTransformer, SegFormerHeadOfficial
+
+    def mk():
+        torch.manual_seed(3)
+        enc = MixVisionTransformer(64, 16, 1, 32, (1, 2, 4, 8), (4, 4, 4, 4), True, 0.0, (1, 1, 1, 1), (8, 4, 2, 1),
+                                   compute_dtype=torch.float32)
+        return SegFormerHeadOfficial(enc, [32, 64, 128, 256], 3, 0.0, 64, compute_dtype=torch.float32).to(dev)
+
+    whole, mine = mk(), mk()
+    assert parallel.convert_sync_batchnorm(mine) >= 1 and parallel.convert_sync_batchnorm(whole, None) >= 1
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 1, 64, 64, 64, generator=g).to(dev)
+    r = torch.randn(2, 3, 64, 64, 64, generator=g).to(dev)
+    ya = whole((x, None, None))
+    (ya.float() * r).sum().backward()
+    yb = mine((x[rk:rk + 1], None, None))
+    (yb.float() * r[rk:rk + 1]).sum().backward()
+    err = float((yb.float() - ya[rk:rk + 1].float()).abs().max()) / float(ya.float().abs().max())
+    assert err < 1e-4, err
+    bw, bm = whole.linear_fuse.bn, mine.linear_fuse.bn
+    assert torch.allclose(bm.running_mean, bw.running_mean, atol=1e-5) and torch.allclose(bm.running_var, bw.running_var, atol=1e-5)
+    pw = dict(whole.named_parameters())
+    for name, p in mine.named_parameters():
+        if name.endswith("linear_pred.weight") or name.endswith("patch_embed1.proj.weight"):
+            gm = p.grad.clone()
+            torch.distributed.all_reduce(gm)
+            ref = pw[name].grad
+            e = float((gm - ref).norm() / ref.norm())
+            assert e < 1e-3, (name, e)
 
 
 if __name__ == "__main__":
