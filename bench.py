@@ -75,6 +75,7 @@ KERNEL_NAMES = {
     "conv3d_k3_fwd/v2": ("igemm_fwd_kernel<27,DIRECT,STORE,2,4,8,4> (conv3d k3 fwd + dgrad, 2x4x8 tiles)", ("igemm_fwd_kernel<27,2x4x8>",)),
     "conv3d_k3_wgrad/v3": ("k3wg_pp_kernel (conv3d k3 weight gradient, 32-channel block pairs, ping-pong)", ("k3wg_pp_kernel",)),
     "conv3d_k3_wgrad/v0": ("igemm_wgrad_kernel<27> (conv3d k3 weight gradient, generic)", ("igemm_wgrad_kernel<27>",)),
+    "conv3d_k3_small": ("k3s_kernel (conv3d k3 fwd + dgrad on 12^3 / 6^3 grids, split-K over workgroups)", ("k3s_kernel",)),
 }
 MFMA_BOUND_FLOP_PER_BYTE = 60.0   # groups above this algorithmic intensity are priced against the MFMA peak, the rest against HBM
 
@@ -209,7 +210,7 @@ def cpu_baseline_sw(size, n_cls, n_windows, sw_batch=4, budget_s=25.0):
                       f"weighted blend), {per_win:.3f} s/window, extrapolated to the {n_windows} windows of one volume"}
 
 
-def roofline_from_timer(summ, ksumm, dtype, step_ms, instr_steps):
+def roofline_from_timer(summ, ksumm, dtype, step_ms, instr_steps, top=5):
     """The roofline object of the step's DOMINANT group -- the timer group with the largest measured total time (every
     entry point of the library is bracketed by HIP events on the launch stream while the timer is on) -- plus the top
     five groups.  `achieved` of the dominant group = its algorithmic flops (or bytes) / the duration of its MAIN kernel
@@ -226,7 +227,7 @@ def roofline_from_timer(summ, ksumm, dtype, step_ms, instr_steps):
         ms = v["total_ms"]
         kern_ms = sum(ksumm[n]["total_ms"] for n in knames if n in ksumm) if ksumm else 0.0
         kern_n = sum(ksumm[n]["launches"] for n in knames if n in ksumm) if ksumm else 0
-        own = kern_ms if (kern_ms > 0 and kern_n == v["launches"]) else None   # the main kernel alone, else the entry point
+        own = kern_ms if (kern_ms > 0 and kern_n >= v["launches"]) else None   # the main kernel(s) alone, else the entry point
         t = (own if own is not None else ms) * 1e-3
         g = {"name": desc, "group": kid, "launches_per_step": round(v["launches"] / instr_steps, 1),
              "share_of_step": round((ms / instr_steps) / step_ms, 3), "avg_ms": round(ms / v["launches"], 4),
@@ -243,7 +244,7 @@ def roofline_from_timer(summ, ksumm, dtype, step_ms, instr_steps):
         return g
 
     order = sorted(summ, key=lambda k: -summ[k]["total_ms"])
-    groups = [price(k, summ[k]) for k in order[:5]]
+    groups = [price(k, summ[k]) for k in order[:top]]
     kid = order[0]
     k, top = summ[kid], groups[0]
     traffic = tshape = None
@@ -411,6 +412,7 @@ def main():
     ap.add_argument("--no-sliding-window", action="store_true",
                     help="default workload only: skip the 512^3 sliding-window leg (the second half of BASELINE.json's metric)")
     ap.add_argument("--sw-steps", type=int, default=3, help="timed 512^3 volumes of the sliding-window leg of the default line")
+    ap.add_argument("--all-groups", action="store_true", help="list every timer group in roofline.groups, not the top five")
     ap.add_argument("--sw-size", type=int, default=512)
     ap.add_argument("--sw-batch", type=int, default=8)   # windows per forward
     args = ap.parse_args()
@@ -625,7 +627,8 @@ def main():
     if rank == 0:
         scale = (args.size / 96.0) ** 3
         step_ms = dt * 1e3 / args.steps
-        res["roofline"] = roofline_from_timer(hip.TIMER.summary(), hip.ktimer_summary(), args.dtype, step_ms, instr_steps)
+        res["roofline"] = roofline_from_timer(hip.TIMER.summary(), hip.ktimer_summary(), args.dtype, step_ms, instr_steps,
+                                              top=1000 if args.all_groups else 5)
         if w["gflop_per_vol"] is not None:
             res["model_tflops"] = round(value / world * w["gflop_per_vol"] * scale / 1e3, 2)
             res["hbm_roofline_frac_algorithmic"] = round(value / world * w["gb_per_vol_bf16"] * scale *

@@ -209,6 +209,31 @@ int msseg_deconv_k2s2_wgrad(const void* x, long long ldx, const void* dy, long l
                             void* workspace, size_t workspace_bytes, int dtype, msseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * conv3d k3 s1 p1 on SMALL grids (12^3 / 6^3 levels of the UNet; csrc/conv3d_k3_small.hip), bf16: the 32-channel stages of a
+ * layer are split over workgroups (split-K), the fp32 partial blocks part[stage group][Cout/4][N*D*H*W][4] are combined by a finish
+ * kernel that also does what follows the conv -- forward: bias, bf16 raw output, InstanceNorm statistics, normalise +
+ * LeakyReLU, optional 2x2x2 max-pool (MONAI TwoConv / Down); input gradient: either the plain sum, or the
+ * whole backward of the conv + InstanceNorm + LeakyReLU unit whose activation was the conv's input (dy of that unit, its
+ * dgamma / dbeta).  wp: msseg_pack_weights image with cout block 32 (forward image, or the flipped / transposed input-
+ * gradient image).  D a multiple of 6 (3 for the tiles, even for the pool), H, W multiples of 6, D*H*W <= 2048; channels
+ * multiples of 32; N <= 8.
+ * ------------------------------------------------------------------------------------------- */
+int msseg_conv3d_k3_small_ok(int N, int D, int H, int W, int Cin, int Cout, int dtype);
+/* number of partial blocks per output element the partials call writes (= `nstages` of the finish calls) */
+int msseg_conv3d_k3_small_stage_groups(int N, int D, int H, int W, int Cin, int Cout);
+size_t msseg_conv3d_k3_small_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout);
+int msseg_conv3d_k3_small_partials(const void* x, long long ldx, const void* wp, float* part, size_t part_bytes, int N,
+                                   int D, int H, int W, int Cin, int Cout, msseg_stream_t stream);
+int msseg_conv3d_k3_small_fwd_finish(const float* part, int nstages, const float* bias, const float* gamma,
+                                     const float* beta, float eps, float slope, void* yraw, long long ldy, void* act,
+                                     long long lda, void* pooled, long long ldp, float* stats, int N, int D, int H, int W,
+                                     int Cout, msseg_stream_t stream);
+int msseg_conv3d_k3_small_bwd_finish(const float* part, int nstages, void* dx, long long lddx, const void* unit_yraw,
+                                     long long lduy, const float* unit_stats, const float* unit_gamma,
+                                     const float* unit_beta, float eps, float slope, float* dgamma, float* dbeta,
+                                     int accumulate, int N, int D, int H, int W, int Cin, msseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Depthwise Conv3d k3 s1 p1 (groups = channels) of the SwinDepth MLP (models/backbones/swindepth.py:36-41,56-65).
  * x, y channels-last [N, D, H, W, C] (C % (16 / sizeof(elem)) == 0); w_taps = the weight [C, 1, 3, 3, 3] transposed to
  * tap-major [27][C] in the tensors' dtype; flip = 1 mirrors the taps (the input gradient: dx = dwconv(dy, flip)).

@@ -114,6 +114,14 @@ SIGNATURES = {
     "msseg_aug_crop_batch": ([_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp], _i),
     "msseg_sw_gather_batch": ([_vp, _ll, _vp, _ll, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
     "msseg_sw_blend_batch": ([_vp, _ll, _i, _vp, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_conv3d_k3_small_ok": ([_i, _i, _i, _i, _i, _i, _i], _i),
+    "msseg_conv3d_k3_small_workspace_bytes": ([_i, _i, _i, _i, _i, _i], _sz),
+    "msseg_conv3d_k3_small_stage_groups": ([_i, _i, _i, _i, _i, _i], _i),
+    "msseg_conv3d_k3_small_partials": ([_vp, _ll, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_conv3d_k3_small_fwd_finish": ([_vp, _i, _vp, _vp, _vp, _f, _f, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i,
+                                          _i, _vp], _i),
+    "msseg_conv3d_k3_small_bwd_finish": ([_vp, _i, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _i,
+                                          _i, _vp], _i),
     "msseg_avgpool3d_k3": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_hd_edges": ([_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
     "msseg_hd_directed_workspace_bytes": ([_i, _i, _i], _sz),
@@ -262,14 +270,14 @@ def pack_weights_batch(table: torch.Tensor, njobs: int, max_total: int, dtype: t
     _ck(lib().msseg_pack_weights_batch(_p(table), njobs, max_total, _DT[dtype], _stream()), "pack_weights_batch")
 
 
-def pack_conv_k3(w: torch.Tensor, dtype, dgrad=False, out=None, vol=None):
+def pack_conv_k3(w: torch.Tensor, dtype, dgrad=False, out=None, vol=None, cb=None):
     """w: [Cout, Cin, 3,3,3] fp32.  Forward image W[co][tap][ci]; dgrad image W'[ci][26-tap][co].
-    vol = (N, D, H, W) of the stride-1 problem the image will be used for (selects the cout block)."""
+    vol = (N, D, H, W) of the stride-1 problem the image will be used for (selects the cout block), or cb = the block."""
     co, ci = w.shape[0], w.shape[1]
     if not dgrad:
-        cb = conv_k3_cout_block(*vol, co) if vol is not None else None
+        cb = cb or (conv_k3_cout_block(*vol, co) if vol is not None else None)
         return pack_weights(w, dtype, co, co, 27, ci, ci, 0, ci * 27, 1, 0, 27, False, out, cb)
-    cb = conv_k3_cout_block(*vol, ci) if vol is not None else None
+    cb = cb or (conv_k3_cout_block(*vol, ci) if vol is not None else None)
     return pack_weights(w, dtype, ci, ci, 27, co, co, 0, 27, 1, 0, ci * 27, True, out, cb)
 
 
@@ -343,7 +351,7 @@ class KernelTimer:
 
 class _TimedLib:
     """what `lib()` returns while TIMER.enabled: every launching entry point goes through TIMER.call"""
-    _QUERY = ("_bytes", "_block", "_variant", "_kernel", "abi_version", "last_error", "num_cus")
+    _QUERY = ("_bytes", "_block", "_variant", "_kernel", "_ok", "_groups", "abi_version", "last_error", "num_cus")
 
     def __init__(self, real):
         self._real = real
@@ -439,6 +447,69 @@ def conv3d_k3_dgrad_inbwd(dy, wp, da, cin, cout, yraw, act, fwd_stats, slope, ep
         key += "/v%d" % lib().msseg_conv3d_k3_kernel(N, D, H, W, cin, cout, dt(dy))
     TIMER.launch(key, 2.0 * nv * 27 * cin * cout, nv * (cin + 3 * cout) * esz + 27 * cin * cout * esz, go)
     return red
+
+
+# --------------------------------------------------------------------------------------------
+# conv k3 on small grids: split-K partials + a finish kernel that carries the rest of the unit (conv3d_k3_small.hip)
+# --------------------------------------------------------------------------------------------
+def conv3d_k3_small_ok(x, cin, cout) -> bool:
+    """can the split-K small-grid path run conv k3 cin -> cout on a volume shaped like x ([N, D, H, W, C])?"""
+    if os.environ.get("MSSEG_NO_K3_SMALL") or x.dim() != 5 or x.dtype != torch.bfloat16:
+        return False
+    N, D, H, W = x.shape[:4]
+    return bool(lib().msseg_conv3d_k3_small_ok(N, D, H, W, cin, cout, BF16))
+
+
+_k3s_ws = {}
+
+
+def _k3s_workspace(nbytes, device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _k3s_ws.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)       # captured graphs keep the old address
+        buf = torch.empty(max(nbytes, 32 << 20) // 4, dtype=torch.float32, device=device)
+        _k3s_ws[key] = buf
+    return buf
+
+
+def conv3d_k3_small_partials(x, wp, cin, cout):
+    """(fp32 partial sums [stage groups][N * D * H * W][cout] of conv k3 (x, packed image with cout block 32), number of
+    stage groups); the buffer is the module's grow-only scratch: consume it (a *_finish call) before the next partials
+    call on the stream"""
+    _need_gpu(x, wp)
+    N, D, H, W = x.shape[:4]
+    nv = N * D * H * W
+    ng = lib().msseg_conv3d_k3_small_stage_groups(N, D, H, W, cin, cout)
+    part = _k3s_workspace(lib().msseg_conv3d_k3_small_workspace_bytes(N, D, H, W, cin, cout), x.device)
+    TIMER.launch("conv3d_k3_small", 2.0 * nv * 27 * cin * cout, nv * (cin * x.element_size() + ng * cout * 4) + 27 * cin * cout * 2,
+                 lambda: _ck(lib().msseg_conv3d_k3_small_partials(_p(x), ld(x), _p(wp), _p(part), part.numel() * 4, N, D, H, W, cin,
+                                                                  cout, _stream()), "conv3d_k3_small_partials"))
+    return part, ng
+
+
+def conv3d_k3_small_fwd_finish(part, nstages, bias, gamma, beta, eps, slope, yraw, act, pooled, stats):
+    _need_gpu(part, yraw, act, stats)
+    N, D, H, W, cout = yraw.shape
+    _ck(lib().msseg_conv3d_k3_small_fwd_finish(_p(part), nstages, _p(bias), _p(gamma), _p(beta), eps, slope, _p(yraw), ld(yraw),
+                                               _p(act), ld(act), _p(pooled), ld(pooled) if pooled is not None else 0,
+                                               _p(stats), N, D, H, W, cout, _stream()), "conv3d_k3_small_fwd_finish")
+
+
+def conv3d_k3_small_bwd_finish(part, nstages, dx, unit=None, dgamma=None, dbeta=None, accumulate=False):
+    """unit = (yraw, stats, gamma, beta, eps, slope) of the conv + InstanceNorm + LeakyReLU unit whose activation was the
+    conv's input: dx then receives that unit's dy (and dgamma / dbeta its affine gradients); None: dx = the plain sum"""
+    _need_gpu(part, dx)
+    N, D, H, W, cin = dx.shape
+    uy = ustats = ug = ub = None
+    eps, slope = 1e-5, 1.0
+    if unit is not None:
+        uy, ustats, ug, ub, eps, slope = unit
+    _ck(lib().msseg_conv3d_k3_small_bwd_finish(_p(part), nstages, _p(dx), ld(dx), _p(uy), ld(uy) if uy is not None else 0,
+                                               _p(ustats), _p(ug), _p(ub), eps, slope, _p(dgamma), _p(dbeta),
+                                               int(accumulate), N, D, H, W, cin, _stream()), "conv3d_k3_small_bwd_finish")
+    return dx
 
 
 def conv3d_k1_head(x, w, bias, y, cin, cout):

@@ -196,6 +196,17 @@ class _WgradSide:
 WGRAD_SIDE = _WgradSide()
 
 
+class _Applied:
+    """what Conv3.bwd returns in place of the InstanceNorm-backward sums when its finish kernel already ran the receiving
+    unit's whole backward (small-grid path): the tensor it returned IS that unit's dy"""
+
+    def __repr__(self):
+        return "APPLIED"
+
+
+APPLIED = _Applied()
+
+
 def _grad_buf(p: torch.nn.Parameter):
     """(tensor to write the gradient into, accumulate?)"""
     if p.grad is None:
@@ -277,6 +288,18 @@ class Conv3:
         if self._gather(dtype):
             raise NotImplementedError("input gradient of a few-channel stem conv is never needed on this path")
         vol = tuple(dy.shape[:4])
+        if hip.conv3d_k3_small_ok(dy, self.cout, self.cin):
+            # small grid: split-K partials, then ONE finish kernel = the plain sum, or the receiving unit's whole backward
+            wp = self.cache.get(self.w, dtype, "ds", lambda: hip.pack_conv_k3(self.w.detach(), dtype, dgrad=True, cb=32))
+            part, ng = hip.conv3d_k3_small_partials(dy, wp, self.cout, self.cin)
+            dx = dx_out if dx_out is not None else _empty_like_vol(dy, self.cin)
+            if next_norm is not None:
+                nrm, yraw, stats, act = next_norm
+                dg, db, acc = _norm_grad_bufs(nrm)
+                hip.conv3d_k3_small_bwd_finish(part, ng, dx, (yraw, stats, nrm.gamma, nrm.beta, nrm.eps, nrm.slope),
+                                               dg, db, acc)
+                return dx, APPLIED
+            return hip.conv3d_k3_small_bwd_finish(part, ng, dx)
         wp = self.cache.get(self.w, dtype, ("d", vol),
                             lambda: hip.pack_conv_k3(self.w.detach(), dtype, dgrad=True, vol=vol))
         dx = dx_out if dx_out is not None else _empty_like_vol(dy, self.cin)
@@ -480,7 +503,12 @@ class InstNormAct:
         return da, red
 
     def bwd(self, y_raw, stats, a, da, want_dres=False, red=None):
-        """red: reductions already produced by the kernel that made `da` (fused path) -> only the apply pass runs"""
+        """red: reductions already produced by the kernel that made `da` (fused path) -> only the apply pass runs;
+        red is APPLIED: `da` already IS this unit's dy (the producer's finish kernel ran the whole backward)"""
+        if red is APPLIED:
+            if want_dres:
+                raise RuntimeError("a residual unit cannot take an already-applied gradient")
+            return da
         dy = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device)
         dres = torch.empty(y_raw.shape, dtype=y_raw.dtype, device=y_raw.device) if want_dres else None
         # without a residual the sign of the pre-activation is recomputed from y_raw: one tensor read less
@@ -505,6 +533,18 @@ class ConvNormAct:
         self.conv, self.norm = conv, norm
 
     def fwd(self, x, out=None, pooled=None):
+        cv, nm = self.conv, self.norm
+        if (not cv._gather(x.dtype) and hip.conv3d_k3_small_ok(x, cv.cin, cv.cout)
+                and (pooled is None or hip.instnorm_pool_ok(x, x, pooled))):
+            # small grid (12^3 / 6^3 levels): split-K partials + one finish kernel for bias, raw output, statistics,
+            # normalise + LeakyReLU and the max-pool -- 2 launches instead of conv, finalize, normalise (+ pool)
+            wp = cv.cache.get(cv.w, x.dtype, "fs", lambda: hip.pack_conv_k3(cv.w.detach(), x.dtype, cb=32))
+            part, ng = hip.conv3d_k3_small_partials(x, wp, cv.cin, cv.cout)
+            y = _empty_like_vol(x, cv.cout)
+            a = out if out is not None else _empty_like_vol(x, cv.cout)
+            stats = torch.empty(x.shape[0], cv.cout, 2, dtype=torch.float32, device=x.device)
+            hip.conv3d_k3_small_fwd_finish(part, ng, cv.b, nm.gamma, nm.beta, nm.eps, nm.slope, y, a, pooled, stats)
+            return a, (x, y, stats, a)
         y, stats = self.conv.fwd(x, want_stats=True)
         a, stats = self.norm.fwd(y, out, stats=stats, pooled=pooled)
         return a, (x, y, stats, a)

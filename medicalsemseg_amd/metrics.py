@@ -39,7 +39,8 @@ def _percentile_from_hist(counts: np.ndarray, q: float) -> float:
 
 def hausdorff95(pred: torch.Tensor, label: torch.Tensor, n_classes: int, percentile: float = 95.0) -> np.ndarray:
     """pred, label: integer label maps [B, D, H, W] (or [B, 1, D, H, W]) on the GPU -> hd [B, n_classes] float64 (host):
-    NaN where neither map has the class, inf where only one has it (MONAI's get_surface_distance conventions)."""
+    NaN where neither map has the class and, with numpy >= 1.22's percentile, also where only one has it (MONAI's
+    get_surface_distance yields all-inf distances there; see below)."""
     if not pred.is_cuda or not label.is_cuda:
         raise RuntimeError("hausdorff95 runs on the GPU only (no CPU fallback; the scipy restatement is oracle/postproc.py)")
     if pred.dim() == 5:
@@ -59,7 +60,11 @@ def hausdorff95(pred: torch.Tensor, label: torch.Tensor, n_classes: int, percent
             if n_p == 0 and n_g == 0:
                 continue                                  # class absent from both maps: NaN
             if n_p == 0 or n_g == 0:
-                hd[b, c] = np.inf                         # one surface empty: every distance is inf in both directions
+                # one surface empty: MONAI's get_surface_distance hands np.percentile an all-inf array in both directions.
+                # numpy (>= 1.22, incl. the 2.2 here) interpolates as a + (b - a) * t: inf - inf -> NaN, so the class drops
+                # out of the mean like an absent one (older numpy gave inf); the same arithmetic, not a constant:
+                with np.errstate(invalid="ignore"):
+                    hd[b, c] = float(np.float64(np.inf) + (np.float64(np.inf) - np.float64(np.inf)) * 0.5)
                 continue
             box = (int(st[c, 0]), int(st[c, 1]), int(st[c, 2]), int(st[c, 3]) + 1, int(st[c, 4]) + 1, int(st[c, 5]) + 1)
             bz, by, bx = box[3] - box[0], box[4] - box[1], box[5] - box[2]

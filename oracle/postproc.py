@@ -49,7 +49,8 @@ def hausdorff95(pred_onehot: np.ndarray, gt_onehot: np.ndarray, percentile: floa
     * ``get_mask_edges``: edges = ``binary_erosion(mask) ^ mask`` (scipy's default 6-neighbour structure, border value 0,
       after a crop to the bounding box of ``pred | gt``, which changes neither edge set nor distances);
     * ``get_surface_distance``: ``distance_transform_edt(~edges_other)`` (voxel units) read at this mask's edge voxels;
-      ``inf`` for every voxel when either edge set is empty, an EMPTY array when both are (-> NaN);
+      ``inf`` for every voxel when either edge set is empty (``np.percentile`` of an all-inf array is NaN with numpy >= 1.22:
+      ``inf - inf`` in its interpolation; older numpy returned inf), an EMPTY array when both are (-> NaN);
     * ``np.percentile(distances, 95)`` per direction, the larger of the two directions."""
     from scipy.ndimage import binary_erosion, distance_transform_edt
 

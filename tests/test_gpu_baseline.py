@@ -117,8 +117,9 @@ def test_unet_base_96_vs_oracle(dtype):
         assert dl < 1e-4 and tot < 1e-3
         assert max(abs(a - b) for a, b in zip(hd, hd_ref)) < 1e-3
     else:
-        # measured on MI355X: drift 1.2e-2 of scale, gradients 9.6e-3 -> gates at about twice that
-        assert drift < 2.5e-2 and tot < 2e-2 and dl < 5e-3
+        # measured on MI355X (round 3): drift 1.24e-2 of scale, gradients 3.7e-3, |loss diff| 1.7e-4, soft-Dice term 2.5e-5
+        # -> gates at about twice that
+        assert drift < 2.5e-2 and tot < 8e-3 and dl < 5e-4 and abs(sd - sd_ref) < 1e-4
 
 
 def test_unet_small_config0_64_vs_oracle():
@@ -204,9 +205,9 @@ def test_unet_base_48_vs_oracle(dtype):
         sd, sd_ref = _soft_dice_term(o, y), _soft_dice_term(out_ref.detach(), y)
         print(f"[bf16] UNet base 48^3 soft-Dice term {sd:.6f} vs fp32 oracle {sd_ref:.6f}, |loss diff| "
               f"{abs(float(loss) - float(loss_ref)):.2e}")
-        # gates at about twice the measured values (drift 1.2e-2, gradients 9.6e-3)
-        assert drift < 2.5e-2 and abs(float(loss) - float(loss_ref)) < 5e-3 and tot < 2e-2
-        assert abs(sd - sd_ref) < 1e-3
+        # gates at about twice the measured values (drift 1.17e-2, gradients 9.6e-3, |loss diff| 1.8e-4, soft Dice 3.3e-5)
+        assert drift < 2.5e-2 and abs(float(loss) - float(loss_ref)) < 5e-4 and tot < 2e-2
+        assert abs(sd - sd_ref) < 1e-4
         # tight forward check: the oracle on bf16-rounded weights with bf16-rounded stored tensors
         ref16 = BasicUNet(1, 3, UNET_FEATURES["UNet"])
         ref16.load_state_dict({k: (v.to(torch.bfloat16).float() if v.dim() > 1 else v) for k, v in ref.state_dict().items()})
@@ -247,7 +248,7 @@ def test_unet_base_96_full_size_step_properties():
 
     net32, l32, g32 = grads(torch.float32)
     net, l16, g16 = grads(torch.bfloat16)
-    assert np.isfinite(l16) and abs(l16 - l32) < 5e-3
+    assert np.isfinite(l16) and abs(l16 - l32) < 5e-4        # measured 1.6e-4
     num = sum(float(((g16[n] - g32[n]) ** 2).sum()) for n in g32 if not (n.endswith("conv.bias") and "final" not in n))
     den = sum(float((g32[n] ** 2).sum()) for n in g32 if not (n.endswith("conv.bias") and "final" not in n))
     rel = (num / den) ** 0.5
@@ -333,8 +334,8 @@ def test_swin_unetr_48_config_vs_oracle(dtype):
     print(f"[{dtype}] Swin-UNETR-48 96^3 soft-Dice term {sd:.6f} vs oracle {sd_ref:.6f}")
     assert abs(sd - sd_ref) < 1e-3
     if dtype == torch.bfloat16:
-        # measured: logits 8.0e-3 of scale, gradients 2.5e-3 -> gates at about twice that
-        assert err < 1.6e-2 and abs(float(loss) - float(loss_ref)) < 5e-3 and tot < 6e-3
+        # measured: logits 8.9e-3 of scale, gradients 2.5e-3, |loss diff| 3.9e-4, soft Dice 7e-5 -> gates at about twice that
+        assert err < 1.8e-2 and abs(float(loss) - float(loss_ref)) < 1e-3 and tot < 6e-3 and abs(sd - sd_ref) < 2e-4
 
 
 def _unet_pair(dtype=torch.float32):
@@ -412,7 +413,7 @@ def test_sliding_window_512_properties():
     print(f"512^3 sub-cube: {n} windows recomputed by the fp32 CPU oracle, bf16 product max err / scale {err:.3e}, "
           f"arg-max agreement {agree:.4f}")
     # bf16 network against the fp32 oracle: the whole-net drift is 1.2e-2 of scale (test_unet_base_*), gate at twice that
-    assert err < 2.5e-2 and agree > 0.97
+    assert err < 2.5e-2 and agree > 0.99          # measured 1.0e-2 / 0.9962
 
 
 def test_sliding_window_sharded_two_ranks_equals_single_rank():

@@ -366,14 +366,11 @@ def test_hausdorff95_bit_exact_vs_scipy_oracle():
     print("hausdorff95 oracle:", want.tolist(), "device:", got.tolist())
     assert got.shape == want.shape == (2, C)
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want[:, 5]).all()
-    assert np.isinf(want[0, 4]) and np.isinf(want[1, 3])
+    # a class only one map has: all-inf distances, which np.percentile (numpy >= 1.22) turns into NaN (inf - inf in its lerp)
+    assert np.isnan(want[0, 4]) and np.isnan(want[1, 3])
     fin = np.isfinite(want)
-    assert np.array_equal(np.isinf(got), np.isinf(want))
-    assert np.array_equal(got[fin], want[fin]), (got, want)        # bit-exact doubles
-    (gv, gn), (wv, wn) = metrics.hausdorff_mean(got), hausdorff_mean(want)
-    assert gn == wn and (gv == wv or (np.isinf(gv) and np.isinf(wv)))
-    # finite means too: drop the inf classes
-    assert metrics.hausdorff_mean(got[:, :3]) == hausdorff_mean(want[:, :3])
+    assert fin.sum() == 7 and np.array_equal(got[fin], want[fin]), (got, want)        # bit-exact doubles
+    assert metrics.hausdorff_mean(got) == hausdorff_mean(want)
 
 
 def test_overlapped_gradient_exchange_equals_plain_exchange_two_ranks():

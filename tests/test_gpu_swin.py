@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 # bf16 whole-net gates (logits err / scale, |loss difference|, whole-net gradient rel-L2) vs the fp32 CPU oracle: about twice
 # the values measured on MI355X (printed by the tests), so that a 2-3x regression of the bf16 path fails
-BF16_GATES = {"swin32": (3e-2, 1e-2, 5e-2), "official64": (2e-2, 1e-2, 4e-2)}
+BF16_GATES = {"swin32": (1.6e-2, 1e-3, 4.5e-2),      # measured 7.8e-3, 7e-6, 2.1e-2
+              "official64": (2e-2, 5e-3, 4e-2)}      # measured 1.03e-2, -, 1.9e-2
 DEV = "cuda:0"
 
 

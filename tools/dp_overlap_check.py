@@ -118,30 +118,35 @@ def dp_equivalence(rank, dev):
         opt = FlatAdamW(add_weight_decay(net, 1e-5), lr=1e-3, betas=(0.9, 0.95), eps=1e-6)
         crit = DiceCELoss()
         gs = parallel.GradSync(opt, net) if sync else None
-        for _ in range(3):
+        g1 = None
+        for it in range(3):
             crit(net((x, None, None)), y).backward()
             if gs is not None:
                 if gs.overlapped:
                     gs.start()
                     net.backward_tail()
                 gs.finish()
+            if it == 0:
+                g1 = (opt.flat_grad * opt._gscale).clone()    # the gradient the first step applies (1 / world folded in)
             opt.step()
             opt.zero_grad()
         torch.cuda.synchronize()
         net.defer_backward_tail(False)
-        return opt.flat_param.clone()
+        return g1, opt.flat_param.clone()
 
     sl = slice(2 * rank, 2 * rank + 2)
-    p_dp = steps(X[sl], Y[sl], True)
+    g_dp, p_dp = steps(X[sl], Y[sl], True)
     torch.distributed.barrier()
     if rank == 0:
-        p_one = steps(X, Y, False)
+        g_one, p_one = steps(X, Y, False)
+        gerr = float((g_dp - g_one).norm() / g_one.norm())
         err = float((p_dp - p_one).abs().max())
-        rel = float((p_dp - p_one).norm() / p_one.norm())
-        print(f"DP_EQUIV max |dp - single| = {err:.3e}, rel-L2 {rel:.3e} over {p_one.numel()} parameters", flush=True)
-        # AdamW's first steps move every parameter by ~lr whatever the gradient's size, and a sign flip of a ~0 gradient
-        # entry moves it by 2 lr: the gate is a few lr on single entries and tight in the norm
-        assert err < 4e-3 and rel < 2e-4, (err, rel)
+        print(f"DP_EQUIV first-step gradient rel-L2 {gerr:.3e}; after 3 AdamW steps max |dp - single| = {err:.3e} over "
+              f"{p_one.numel()} parameters", flush=True)
+        # the averaged rank gradients ARE the whole-batch gradient up to fp32 summation order; AdamW then moves every
+        # parameter by ~lr per step whatever the gradient's size (a sign flip of a ~0 entry costs 2 lr), so parameters are
+        # only gated at a few lr
+        assert gerr < 1e-4 and err < 4e-3, (gerr, err)
     torch.distributed.barrier()
 
 
