@@ -30,6 +30,8 @@
 // rows on an 8-wide halo cost a 2-way bank conflict on part of the voxel-operand reads).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int TS = 6;                       // tile edge (h, w)
@@ -170,97 +172,96 @@ struct K3sFinParams {
     const bf16_t* uy; long long lduy;            // receiving unit: raw conv output, forward statistics, affine
     const float* ustats; const float* ugamma; const float* ubeta;
     float* dgamma; float* dbeta; int acc;
+    int dbg;                                     // timing experiments only (MSSEG_K3S_DBG): 1 = no output stores, 2 = no partial loads
 };
 
 constexpr int FCH = 4;        // channels of a finish workgroup (one float4 per stage group and voxel)
-constexpr int NKG_MAX = 8;    // stage groups (all their loads of a thread are in flight together)
+constexpr int NKG_MAX = 8;    // stage groups
 
 MSSEG_DEVFN void store4_bf16(bf16_t* p, const float* v) {
     bf16x4_t o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
     *(bf16x4_t*)p = o;
 }
 
-// fixed-order sum of 8 per-thread values over the BS threads of the block: lanes by xor-shuffles, waves in order
-template <int BS>
-MSSEG_DEVFN void block_sum8(float* v, float* lds /* >= (BS / 64) * 8 floats */) {
+// fixed-order sum of NV per-thread values over the BS threads of the block: lanes by xor-shuffles, then the per-wave rows
+// are added in wave order by the first NV threads and broadcast through LDS.  lds: >= (BS / 64 + 1) * NV floats.
+template <int BS, int NV>
+MSSEG_DEVFN void block_sum(float* v, float* lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = wave_sum(v[e]);
+    for (int e = 0; e < NV; ++e) v[e] = wave_sum(v[e]);
     __syncthreads();                                  // lds may still be read from a previous call
     if (lane == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) lds[wave * 8 + e] = v[e];
+        for (int e = 0; e < NV; ++e) lds[wave * NV + e] = v[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float t = lds[threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < BS / 64; ++w) t += lds[w * NV + threadIdx.x];
+        lds[(BS / 64) * NV + threadIdx.x] = t;
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float t = lds[e];
-        for (int w = 1; w < BS / 64; ++w) t += lds[w * 8 + e];
-        v[e] = t;
-    }
+    for (int e = 0; e < NV; ++e) v[e] = lds[(BS / 64) * NV + e];
 }
 
-// sum of the stage groups of VPT voxels x FCH channels; the loads of a voxel (SEQ: register-tight kernels) or of all the
-// thread's voxels are issued before the first use
-template <int BS, int VPT, bool SEQ = false>
-MSSEG_DEVFN void sum_partials(const K3sFinParams& p, int n, int S, int c0, float (&a)[VPT][FCH]) {
-    if constexpr (SEQ) {
-#pragma nounroll
-        for (int i = 0; i < VPT; ++i) {
-            const int v = threadIdx.x + i * BS;
-            const float* src = p.part + ((long long)(c0 >> 2) * p.NV + (long long)n * S + (v < S ? v : 0)) * 4;
-            f32x4_t t[NKG_MAX];
+// sum over the stage groups of the partial rows of one (channel group, item): every load of the thread's NI items is issued
+// before the first use (NKG = groups the kernel is built for; absent groups add exact zeros, the order is fixed)
+// NIC: items whose loads are in flight together (register-tight kernels take their items in chunks)
+template <int NI, int NKG, int NIC = NI>
+MSSEG_DEVFN void sum_partials(const K3sFinParams& p, int cg, const long long (&row)[NI], const bool (&ok)[NI], float (&a)[NI][FCH]) {
+    static_assert(NI % NIC == 0, "chunks must divide the items");
 #pragma unroll
-            for (int k = 0; k < NKG_MAX; ++k)
-                t[k] = (k < p.nks && v < S) ? *(const f32x4_t*)(src + (long long)k * p.NV * p.M) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            f32x4_t acc = t[0];
+    for (int c = 0; c < NI; c += NIC) {
+        f32x4_t t[NIC][NKG];
 #pragma unroll
-            for (int k = 1; k < NKG_MAX; ++k) acc += t[k];
+        for (int i = 0; i < NIC; ++i) {
+            const float* src = p.part + ((long long)cg * p.NV + (ok[c + i] ? row[c + i] : 0)) * 4;
 #pragma unroll
-            for (int e = 0; e < FCH; ++e) a[i][e] = acc[e];
+            for (int k = 0; k < NKG; ++k)
+                t[i][k] = (k < p.nks && ok[c + i] && !(p.dbg & 2)) ? *(const f32x4_t*)(src + (long long)k * p.NV * p.M) : f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
-        return;
-    }
-    f32x4_t t[VPT][NKG_MAX];
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int v = threadIdx.x + i * BS;
-        const float* src = p.part + ((long long)(c0 >> 2) * p.NV + (long long)n * S + (v < S ? v : 0)) * 4;
+        for (int i = 0; i < NIC; ++i) {
+            f32x4_t acc = t[i][0];
 #pragma unroll
-        for (int k = 0; k < NKG_MAX; ++k)
-            t[i][k] = (k < p.nks && v < S) ? *(const f32x4_t*)(src + (long long)k * p.NV * p.M) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
+            for (int k = 1; k < NKG; ++k) acc += t[i][k];
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        f32x4_t acc = t[i][0];
-#pragma unroll
-        for (int k = 1; k < NKG_MAX; ++k) acc += t[i][k];     // fixed order; absent groups add exact zeros
-#pragma unroll
-        for (int e = 0; e < FCH; ++e) a[i][e] = acc[e];
+            for (int e = 0; e < FCH; ++e) a[c + i][e] = acc[e];
+        }
+        if (c + NIC < NI) asm volatile("" ::: "memory");   // keep the chunks' loads from being hoisted together
     }
 }
 
 // BS threads, VPT voxels per thread (S <= BS * VPT): 256 x 1 for 6^3, 1024 x 2 for 12^3
-template <int BS, int VPT>
+template <int BS, int VPT, int NKG>
 __global__ __launch_bounds__(BS) void k3s_fwd_finish_kernel(const K3sFinParams p) {
-    __shared__ float red[(BS / 64) * 8];
+    __shared__ float red[(BS / 64 + 1) * 8];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];   // pooled only: the slab's activation [S][4] bf16
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * FCH, n = blockIdx.y;
     const int S = p.D * p.H * p.W;
+    long long row[VPT];
+    bool ok[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) { ok[i] = tid + i * BS < S; row[i] = (long long)n * S + tid + i * BS; }
     float y[VPT][FCH];
-    sum_partials<BS, VPT>(p, n, S, c0, y);
+    sum_partials<VPT, NKG>(p, blockIdx.x, row, ok, y);
+    float bias[FCH];
+#pragma unroll
+    for (int e = 0; e < FCH; ++e) bias[e] = p.bias ? p.bias[c0 + e] : 0.f;
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        const int v = tid + i * BS;
-        if (v < S) {
+        if (ok[i]) {
             bf16x4_t o;
 #pragma unroll
-            for (int e = 0; e < FCH; ++e) o[e] = (bf16_t)(y[i][e] + (p.bias ? p.bias[c0 + e] : 0.f));
-            *(bf16x4_t*)(p.yraw + ((long long)n * S + v) * p.ldy + c0) = o;
+            for (int e = 0; e < FCH; ++e) o[e] = (bf16_t)(y[i][e] + bias[e]);
+            if (!(p.dbg & 1)) *(bf16x4_t*)(p.yraw + row[i] * p.ldy + c0) = o;
 #pragma unroll
             for (int e = 0; e < FCH; ++e) {
                 y[i][e] = (float)o[e];              // statistics of the STORED values, as every conv epilogue takes them
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(BS) void k3s_fwd_finish_kernel(const K3sFinParams p
             }
         }
     }
-    block_sum8<BS>(s, red);
+    block_sum<BS, 8>(s, red);
     if (tid < FCH) {
         p.stats[((long long)n * p.M + c0 + tid) * 2 + 0] = s[tid];
         p.stats[((long long)n * p.M + c0 + tid) * 2 + 1] = s[4 + tid];
@@ -288,16 +289,15 @@ __global__ __launch_bounds__(BS) void k3s_fwd_finish_kernel(const K3sFinParams p
     bf16x4_t* slab = (bf16x4_t*)dyn;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        const int v = tid + i * BS;
-        if (v < S) {
+        if (ok[i]) {
             bf16x4_t o;
 #pragma unroll
             for (int e = 0; e < FCH; ++e) {
                 const float z = y[i][e] * sc[e] + sh[e];
                 o[e] = (bf16_t)(z > 0.f ? z : z * p.slope);
             }
-            *(bf16x4_t*)(p.act + ((long long)n * S + v) * p.lda + c0) = o;
-            if (p.pooled) slab[v] = o;
+            if (!(p.dbg & 1)) *(bf16x4_t*)(p.act + row[i] * p.lda + c0) = o;
+            if (p.pooled) slab[tid + i * BS] = o;
         }
     }
     if (p.pooled) {
@@ -320,12 +320,31 @@ __global__ __launch_bounds__(BS) void k3s_fwd_finish_kernel(const K3sFinParams p
     }
 }
 
-// input-gradient finish.  UNIT = false: dx = sum of the stage groups.  UNIT = true: the conv's input was the activation
-// of a conv + InstanceNorm + LeakyReLU unit (raw output uy, statistics ustats): dx = that unit's dy; one workgroup per 4
-// channels walks the samples, so dgamma / dbeta are complete inside it.
-template <int BS, int VPT, bool UNIT>
-__global__ __launch_bounds__(BS) void k3s_bwd_finish_kernel(const K3sFinParams p) {
-    __shared__ float red[(BS / 64) * 8];
+// input-gradient finish, plain: dx = sum of the stage groups (one workgroup per (sample, 4 channels))
+template <int BS, int VPT, int NKG>
+__global__ __launch_bounds__(BS) void k3s_bwd_plain_kernel(const K3sFinParams p) {
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * FCH, n = blockIdx.y;
+    const int S = p.D * p.H * p.W;
+    long long row[VPT];
+    bool ok[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) { ok[i] = tid + i * BS < S; row[i] = (long long)n * S + tid + i * BS; }
+    float a[VPT][FCH];
+    sum_partials<VPT, NKG>(p, blockIdx.x, row, ok, a);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+        if (ok[i]) store4_bf16(p.dx + row[i] * p.lddx + c0, a[i]);
+}
+
+// input-gradient finish, unit mode: the conv's input was the activation of a conv + InstanceNorm + LeakyReLU unit (raw
+// output uy, statistics ustats): dx = that unit's dy.  One workgroup per 4 channels; it takes the samples TWO at a time
+// (items = (sample, voxel) pairs over both, 2 * VPT per thread), so that a batch of 2 is one round of loads, and keeps
+// the per-channel sums of all samples: dgamma / dbeta are complete inside it.
+template <int BS, int VPT, int NKG>
+__global__ __launch_bounds__(BS) void k3s_bwd_unit_kernel(const K3sFinParams p) {
+    constexpr int NI = 2 * VPT;
+    __shared__ float red[(BS / 64 + 1) * 16];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * FCH;
     const int S = p.D * p.H * p.W;
@@ -333,72 +352,100 @@ __global__ __launch_bounds__(BS) void k3s_bwd_finish_kernel(const K3sFinParams p
     float g0[FCH], g1[FCH];
 #pragma unroll
     for (int e = 0; e < FCH; ++e) g0[e] = g1[e] = 0.f;
-    const int n_lo = UNIT ? 0 : blockIdx.y, n_hi = UNIT ? p.N : blockIdx.y + 1;
-    for (int n = n_lo; n < n_hi; ++n) {
-        float a[VPT][FCH];
-        sum_partials<BS, VPT, (UNIT && BS >= 1024)>(p, n, S, c0, a);
-        if constexpr (!UNIT) {
+    for (int nb = 0; nb < p.N; nb += 2) {
+        const bool two = nb + 1 < p.N;
+        float mean[2][FCH], rstd[2][FCH], ga[FCH], be[FCH];
 #pragma unroll
-            for (int i = 0; i < VPT; ++i) {
-                const int v = tid + i * BS;
-                if (v < S) store4_bf16(p.dx + ((long long)n * S + v) * p.lddx + c0, a[i]);
-            }
-        } else {
-            float sc[FCH], sh[FCH], mean[FCH], rstd[FCH];
+        for (int e = 0; e < FCH; ++e) {
+            ga[e] = p.ugamma ? p.ugamma[c0 + e] : 1.f;
+            be[e] = p.ubeta ? p.ubeta[c0 + e] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = two || j == 0 ? nb + j : nb;
 #pragma unroll
             for (int e = 0; e < FCH; ++e) {
                 const float s0 = p.ustats[((long long)n * p.M + c0 + e) * 2 + 0], s1 = p.ustats[((long long)n * p.M + c0 + e) * 2 + 1];
-                mean[e] = s0 * inv;
-                float var = s1 * inv - mean[e] * mean[e];
+                mean[j][e] = s0 * inv;
+                float var = s1 * inv - mean[j][e] * mean[j][e];
                 var = var > 0.f ? var : 0.f;
-                rstd[e] = rsqrtf(var + p.eps);
-                sc[e] = rstd[e] * (p.ugamma ? p.ugamma[c0 + e] : 1.f);
-                sh[e] = (p.ubeta ? p.ubeta[c0 + e] : 0.f) - mean[e] * sc[e];
+                rstd[j][e] = rsqrtf(var + p.eps);
             }
-            float xh[VPT][FCH];
-            float s[8];
+        }
+        // item i of the thread: sample nb + (i >= VPT), voxel tid + (i % VPT) * BS
+        long long row[NI];
+        bool ok[NI];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        for (int i = 0; i < NI; ++i) {
+            const int j = i / VPT, v = tid + (i % VPT) * BS;
+            ok[i] = v < S && (j == 0 || two);
+            row[i] = (long long)(nb + j) * S + v;
+        }
+        float a[NI][FCH];
+        bf16x4_t yb[NI];
+        sum_partials<NI, NKG, (BS >= 1024 && NKG >= 8) ? NI / 4 : ((BS >= 1024 && NKG >= 4) ? NI / 2 : NI)>(p, blockIdx.x, row, ok, a);
+        float s[16];
 #pragma unroll
-            for (int i = 0; i < VPT; ++i) {
-                const int v = tid + i * BS;
-                if (v < S) {
-                    const bf16x4_t yb = *(const bf16x4_t*)(p.uy + ((long long)n * S + v) * p.lduy + c0);
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
-                    for (int e = 0; e < FCH; ++e) {
-                        // the gradient of the activation as the unfused path stores it (bf16), then the unit's backward
-                        const float da = (float)(bf16_t)a[i][e];
-                        const float yv = (float)yb[e];
-                        const float z = yv * sc[e] + sh[e];
-                        a[i][e] = z > 0.f ? da : da * p.slope;              // dz
-                        xh[i][e] = (yv - mean[e]) * rstd[e];
-                        s[e] += a[i][e];
-                        s[4 + e] += a[i][e] * xh[i][e];
-                    }
+        for (int i = 0; i < NI; ++i) {
+            const int j = i / VPT;
+            if (ok[i]) {
+                yb[i] = *(const bf16x4_t*)(p.uy + row[i] * p.lduy + c0);
+#pragma unroll
+                for (int e = 0; e < FCH; ++e) {
+                    // the gradient of the activation as the unfused path stores it (bf16), then the unit's backward with the
+                    // scale / shift formed exactly as the forward formed them (the sign of the pre-activation must agree)
+                    const float da = (float)(bf16_t)a[i][e];
+                    const float yv = (float)yb[i][e];
+                    const float sc = rstd[j][e] * ga[e];
+                    const float z = yv * sc + (be[e] - mean[j][e] * sc);
+                    a[i][e] = z > 0.f ? da : da * p.slope;              // dz
+                    const float xh = (yv - mean[j][e]) * rstd[j][e];
+                    s[j * 8 + e] += a[i][e];
+                    s[j * 8 + 4 + e] += a[i][e] * xh;
                 }
             }
-            block_sum8<BS>(s, red);
+        }
+        block_sum<BS, 16>(s, red);
 #pragma unroll
-            for (int e = 0; e < FCH; ++e) { g0[e] += s[e]; g1[e] += s[4 + e]; }
+        for (int e = 0; e < FCH; ++e) {        // samples in order: the same sums whatever the pairing
+            g0[e] += s[e]; g1[e] += s[4 + e];
+            if (two) { g0[e] += s[8 + e]; g1[e] += s[12 + e]; }
+        }
 #pragma unroll
-            for (int i = 0; i < VPT; ++i) {
-                const int v = tid + i * BS;
-                if (v < S) {
-                    float o[FCH];
+        for (int i = 0; i < NI; ++i) {
+            const int j = i / VPT;
+            if (ok[i]) {
+                float o[FCH];
 #pragma unroll
-                    for (int e = 0; e < FCH; ++e) o[e] = sc[e] * (a[i][e] - s[e] * inv - xh[i][e] * (s[4 + e] * inv));
-                    store4_bf16(p.dx + ((long long)n * S + v) * p.lddx + c0, o);
+                for (int e = 0; e < FCH; ++e) {
+                    const float xh = ((float)yb[i][e] - mean[j][e]) * rstd[j][e];
+                    o[e] = rstd[j][e] * ga[e] * (a[i][e] - s[j * 8 + e] * inv - xh * (s[j * 8 + 4 + e] * inv));
                 }
+                store4_bf16(p.dx + row[i] * p.lddx + c0, o);
             }
         }
     }
-    if constexpr (UNIT) {
-        if (p.dgamma != nullptr && tid < FCH) {
-            p.dbeta[c0 + tid] = p.acc ? p.dbeta[c0 + tid] + g0[tid] : g0[tid];
-            p.dgamma[c0 + tid] = p.acc ? p.dgamma[c0 + tid] + g1[tid] : g1[tid];
-        }
+    if (p.dgamma != nullptr && tid < FCH) {
+        p.dbeta[c0 + tid] = p.acc ? p.dbeta[c0 + tid] + g0[tid] : g0[tid];
+        p.dgamma[c0 + tid] = p.acc ? p.dgamma[c0 + tid] + g1[tid] : g1[tid];
     }
 }
+
+// kernel instantiations by (block, voxels per thread) x stage groups (2, 4, 8)
+#define K3S_LAUNCH(KERN, grid, lds, s, p, S, nks)                                                         \
+    do {                                                                                                  \
+        if ((S) <= 256) {                                                                                 \
+            if ((nks) <= 2) hipLaunchKernelGGL((KERN<256, 1, 2>), grid, dim3(256), lds, s, p);            \
+            else if ((nks) <= 4) hipLaunchKernelGGL((KERN<256, 1, 4>), grid, dim3(256), lds, s, p);       \
+            else hipLaunchKernelGGL((KERN<256, 1, 8>), grid, dim3(256), lds, s, p);                       \
+        } else {                                                                                          \
+            if ((nks) <= 2) hipLaunchKernelGGL((KERN<1024, 2, 2>), grid, dim3(1024), lds, s, p);          \
+            else if ((nks) <= 4) hipLaunchKernelGGL((KERN<1024, 2, 4>), grid, dim3(1024), lds, s, p);     \
+            else hipLaunchKernelGGL((KERN<1024, 2, 8>), grid, dim3(1024), lds, s, p);                     \
+        }                                                                                                 \
+    } while (0)
 
 int k3s_check(const void* x, long long ldx, const void* wp, const void* part, int N, int D, int H, int W, int K, int M,
               const char* who) {
@@ -480,10 +527,11 @@ int msseg_conv3d_k3_small_fwd_finish(const float* part, int nstages, const float
     p.part = part; p.nks = nstages; p.NV = (long long)N * S; p.N = N; p.D = D; p.H = H; p.W = W; p.M = Cout; p.bias = bias;
     p.gamma = gamma; p.beta = beta; p.eps = eps; p.slope = slope;
     p.yraw = (bf16_t*)yraw; p.ldy = ldy; p.act = (bf16_t*)act; p.lda = lda; p.pooled = (bf16_t*)pooled; p.ldp = ldp; p.stats = stats;
+    static const int dbg = getenv("MSSEG_K3S_DBG") ? atoi(getenv("MSSEG_K3S_DBG")) : 0;
+    p.dbg = dbg;
     const int lds = pooled ? S * 8 : 0;
     dim3 grid(Cout / FCH, N);
-    if (S <= 256) hipLaunchKernelGGL((k3s_fwd_finish_kernel<256, 1>), grid, dim3(256), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((k3s_fwd_finish_kernel<1024, 2>), grid, dim3(1024), lds, (hipStream_t)stream, p);
+    K3S_LAUNCH(k3s_fwd_finish_kernel, grid, lds, (hipStream_t)stream, p, S, nstages);
     MSSEG_CHECK_LAUNCH("conv3d_k3_small_fwd_finish");
     return MSSEG_OK;
 }
@@ -509,12 +557,10 @@ int msseg_conv3d_k3_small_bwd_finish(const float* part, int nstages, void* dx, l
     hipStream_t s = (hipStream_t)stream;
     if (unit_yraw) {
         dim3 grid(Cin / FCH, 1);
-        if (S <= 256) hipLaunchKernelGGL((k3s_bwd_finish_kernel<256, 1, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k3s_bwd_finish_kernel<1024, 2, true>), grid, dim3(1024), 0, s, p);
+        K3S_LAUNCH(k3s_bwd_unit_kernel, grid, 0, s, p, S, nstages);
     } else {
         dim3 grid(Cin / FCH, N);
-        if (S <= 256) hipLaunchKernelGGL((k3s_bwd_finish_kernel<256, 1, false>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k3s_bwd_finish_kernel<1024, 2, false>), grid, dim3(1024), 0, s, p);
+        K3S_LAUNCH(k3s_bwd_plain_kernel, grid, 0, s, p, S, nstages);
     }
     MSSEG_CHECK_LAUNCH("conv3d_k3_small_bwd_finish");
     return MSSEG_OK;
