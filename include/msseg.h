@@ -99,6 +99,13 @@ int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const floa
  * whose activation receives that gradient: da = conv(dy, W'); red[n][c] = (sum dz, sum dz*xhat) with
  * dz = da*lrelu'(act), xhat from (yraw, fwd_stats); dbeta/dgamma (nullable) = sum_n red (written or accumulated).
  * Saves the separate msseg_instnorm_act_bwd_reduce pass (3 tensor reads).  N <= 8, Cout % 4 == 0. */
+/* y += conv3d k3 (x, w) without bias: the stored bf16 values of y are read back and the sums stored; stats = InstanceNorm
+ * statistics of the sums.  Lets a 64-input-channel layer over cat([a, b]) run as two 32-channel launches on the ping-pong
+ * kernel without a concat buffer (inference forward of MONAI BasicUNet's UpCat convs).  Only for shapes the
+ * ping-pong kernel takes (bf16, Cin == 32, Cout % 32 == 0, large grids: msseg_conv3d_k3_kernel() == 3). */
+int msseg_conv3d_k3_fwd_accumulate(const void* x, long long ldx, const void* wp, void* y, long long ldy, int N, int D, int H,
+                                   int W, int Cin, int Cout, float* stats, void* scratch, size_t scratch_bytes, int dtype,
+                                   msseg_stream_t stream);
 int msseg_conv3d_k3_dgrad_inbwd(const void* dy, long long lddy, const void* wp, void* da, long long ldda, int N, int D,
                                 int H, int W, int Cin, int Cout, const void* yraw, long long ldyraw, const void* act,
                                 long long ldact, const float* fwd_stats, float slope, float eps, float* red,

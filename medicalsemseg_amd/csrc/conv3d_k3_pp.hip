@@ -278,6 +278,24 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
             // asm: the compiler would pair them into v_pk_add_f32).
             // all stores first (they are what the phase's closing s_waitcnt vmcnt(0) waits for), the sums afterwards
             u32x2_t ob[TH][2];
+            if constexpr (STATS == 3) {
+                // accumulate mode: this launch's sums are added to the values already stored in y (the first K half of a
+                // 64-input-channel layer run as two 32-channel launches); all loads first
+                u32x2_t yo[TH][2];
+#pragma unroll
+                for (int m = 0; m < TH; ++m)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bool ok = FULL || (okdw && tc.h0 + m < p.H);
+                        yo[m][j] = ok ? *(const u32x2_t*)(ybase + o_off[m] + j * 32) : u32x2_t{0u, 0u};
+                    }
+#pragma unroll
+                for (int m = 0; m < TH; ++m)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[m][j][e] += bf16_of_pair(yo[m][j][e >> 1], e & 1);
+            }
 #pragma unroll
             for (int m = 0; m < TH; ++m)
 #pragma unroll
@@ -297,7 +315,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
                         for (int e = 0; e < 4; ++e) {
                             float v = bf16_of_pair(ob[m][j][e >> 1], e & 1);   // the value as stored
                             if (!FULL) v = ok ? v : 0.f;
-                            if constexpr (STATS == 1) {
+                            if constexpr (STATS == 1 || STATS == 3) {
                                 acc_add(s1[j][e], v);
                                 acc_fma(s2[j][e], v, v);
                             } else {
@@ -401,6 +419,10 @@ bool msseg_k3pp_eligible(const K3ppParams& p) {
 
 int msseg_k3pp_launch(const K3ppParams& p, hipStream_t stream) {
     static const bool timing = getenv("MSSEG_K3PP_TIMING") != nullptr;
+    if (p.accumulate) {
+        if (p.stats == nullptr || p.nb_y != nullptr) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_pp: accumulate mode comes with forward statistics");
+        return launch<3, 0>(p, stream);
+    }
     if (p.stats == nullptr) return timing ? launch<0, 1>(p, stream) : launch<0, 0>(p, stream);
     if (p.nb_y == nullptr) return timing ? launch<1, 1>(p, stream) : launch<1, 0>(p, stream);
     return launch<2, 0>(p, stream);

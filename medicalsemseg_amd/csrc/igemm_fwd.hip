@@ -883,6 +883,25 @@ int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const floa
                        0, nullptr, 0.f, 0.f, nullptr, nullptr, 0, dtype, stream);
 }
 
+int msseg_conv3d_k3_fwd_accumulate(const void* x, long long ldx, const void* wp, void* y, long long ldy, int N, int D, int H,
+                                   int W, int Cin, int Cout, float* stats, void* scratch, size_t scratch_bytes, int dtype,
+                                   msseg_stream_t stream) {
+    if (!x || !wp || !y || !stats) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_fwd_accumulate: null pointer");
+    if (dtype != MSSEG_BF16 || N < 1 || N > MSSEG_STATS_NMAX) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_fwd_accumulate: bf16, N <= %d", MSSEG_STATS_NMAX);
+    if (!scratch || ((uintptr_t)scratch & 255) || scratch_bytes < msseg_reduce_scratch_bytes())
+        MSSEG_FAIL(MSSEG_EWORKSPACE, "conv3d_k3_fwd_accumulate: needs the reduce scratch of %zu bytes", msseg_reduce_scratch_bytes());
+    K3ppParams pp{};
+    pp.x = x; pp.ldx = ldx; pp.wp = wp; pp.y = y; pp.ldy = ldy;
+    pp.N = N; pp.D = D; pp.H = H; pp.W = W; pp.K = Cin; pp.M = Cout;
+    pp.stats = stats; pp.counter = (unsigned int*)scratch;
+    pp.stats_ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
+    pp.accumulate = 1;
+    if (!msseg_k3pp_eligible(pp))
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_fwd_accumulate: only shapes of the ping-pong kernel (32 input channels, Cout %% 32 == 0, "
+                                 "large grids; msseg_conv3d_k3_kernel() == 3)");
+    return msseg_k3pp_launch(pp, (hipStream_t)stream);
+}
+
 int msseg_conv3d_k3_dgrad_inbwd(const void* dy, long long lddy, const void* wp, void* da, long long ldda, int N, int D,
                                 int H, int W, int Cin, int Cout, const void* yraw, long long ldyraw, const void* act,
                                 long long ldact, const float* fwd_stats, float slope, float eps, float* red,

@@ -19,6 +19,7 @@ struct K3ppParams {
     const float* nb_stats;
     float nb_slope, nb_eps; long long nb_S;
     float* nb_dgamma; float* nb_dbeta; int nb_acc;
+    int accumulate;      // 1: y += conv(x) (the stored bf16 values are read back in the epilogue), statistics of the sums
 };
 
 // true when the problem can run on the ping-pong kernel (otherwise the generic igemm kernel is used)

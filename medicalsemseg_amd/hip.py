@@ -35,6 +35,7 @@ SIGNATURES = {
     "msseg_conv3d_k3_variant": ([_i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_kernel": ([_i, _i, _i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
+    "msseg_conv3d_k3_fwd_accumulate": ([_vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_dwconv3d_k3_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_dwconv3d_k3_wgrad": ([_vp, _ll, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_interp_trilinear_fwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -251,7 +252,7 @@ def pack_weights(src: torch.Tensor, dtype: torch.dtype, M, M0, T, K, K0, s_m1, s
                  out: Optional[torch.Tensor] = None, cb: Optional[int] = None) -> torch.Tensor:
     global LAST_PACK_JOB
     _need_gpu(src)
-    assert src.dtype == torch.float32 and src.is_contiguous()
+    assert src.dtype == torch.float32      # any layout the explicit strides describe (a channel slice of a conv weight)
     cb = cb or cout_block(M)
     nbytes = lib().msseg_packed_weight_bytes(M, T, K, cb, _DT[dtype])
     esz = 4 if dtype == torch.float32 else 2
@@ -271,12 +272,15 @@ def pack_weights_batch(table: torch.Tensor, njobs: int, max_total: int, dtype: t
 
 
 def pack_conv_k3(w: torch.Tensor, dtype, dgrad=False, out=None, vol=None, cb=None):
-    """w: [Cout, Cin, 3,3,3] fp32.  Forward image W[co][tap][ci]; dgrad image W'[ci][26-tap][co].
+    """w: [Cout, Cin, 3,3,3] fp32 (dense, or an input-channel slice w_full[:, a:b] of a dense weight: forward image only).
+    Forward image W[co][tap][ci]; dgrad image W'[ci][26-tap][co].
     vol = (N, D, H, W) of the stride-1 problem the image will be used for (selects the cout block), or cb = the block."""
     co, ci = w.shape[0], w.shape[1]
     if not dgrad:
         cb = cb or (conv_k3_cout_block(*vol, co) if vol is not None else None)
-        return pack_weights(w, dtype, co, co, 27, ci, ci, 0, ci * 27, 1, 0, 27, False, out, cb)
+        assert w.stride(1) == 27 and w.stride(4) == 1 and w.stride(0) % 27 == 0
+        return pack_weights(w, dtype, co, co, 27, ci, ci, 0, w.stride(0), 1, 0, 27, False, out, cb)
+    assert w.is_contiguous()
     cb = cb or (conv_k3_cout_block(*vol, ci) if vol is not None else None)
     return pack_weights(w, dtype, ci, ci, 27, co, co, 0, 27, 1, 0, ci * 27, True, out, cb)
 
@@ -423,6 +427,19 @@ def conv3d_k3(x, wp, bias, y, cin, cout, stats=None):
     if TIMER.enabled:
         key += "/v%d" % lib().msseg_conv3d_k3_kernel(N, D, H, W, cin, cout, dt(x))
     TIMER.launch(key, 2.0 * nv * 27 * cin * cout, nv * (cin + cout) * esz + 27 * cin * cout * esz, go)
+    return y
+
+
+def conv3d_k3_accumulate(x, wp, y, cin, cout, stats):
+    """y += conv k3 (x, packed image) on the ping-pong kernel; stats [N, cout, 2] = statistics of the sums"""
+    _need_gpu(x, wp, y, stats)
+    N, D, H, W = x.shape[:4]
+    nv = N * D * H * W
+    sc = scratch(x.device)
+    TIMER.launch("conv3d_k3_fwd/v3", 2.0 * nv * 27 * cin * cout, nv * (cin + 2 * cout) * x.element_size() + 27 * cin * cout * 2,
+                 lambda: _ck(lib().msseg_conv3d_k3_fwd_accumulate(_p(x), ld(x), _p(wp), _p(y), ld(y), N, D, H, W, cin, cout,
+                                                                 _p(stats), _p(sc), sc.numel(), dt(x), _stream()),
+                             "conv3d_k3_fwd_accumulate"))
     return y
 
 

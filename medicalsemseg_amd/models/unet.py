@@ -164,17 +164,23 @@ def _forward_cl(net: "UNet", x, keep: bool):
     dev = x.device
     f = net.features
     saved = {"enc": [], "dec": []}
-    # concat buffers [skip | up] for the 4 decoder levels (level i uses encoder output i)
-    cat = []
+    # concat buffers [skip | up] for the 4 decoder levels (level i uses encoder output i).  Inference (nothing kept): at the
+    # 32 + 32-channel levels the first decoder conv runs as two launches of the ping-pong kernel on the skip and on the
+    # upsampled tensor (Conv3.fwd_split): those levels get two dense tensors instead of the concat buffer.
+    cat, split = [], [False] * 4
     for i in range(4):
         sh = (N, D >> i, H >> i, W >> i)
         up_ch = f[i + 1] // 2 if i > 0 else f[1]
-        cat.append(torch.empty(sh + (f[i] + up_ch,), dtype=T, device=dev))
+        split[i] = (not keep) and net._dec[3 - i][1].conv.split_ok(sh, T, f[i], up_ch)
+        if split[i]:
+            cat.append((torch.empty(sh + (f[i],), dtype=T, device=dev), torch.empty(sh + (up_ch,), dtype=T, device=dev)))
+        else:
+            cat.append(torch.empty(sh + (f[i] + up_ch,), dtype=T, device=dev))
     cur = x
     skips = []
     for lvl, (c0, c1) in enumerate(net._enc):
         a0, s0 = c0.fwd(cur)
-        out = cat[lvl][..., :f[lvl]] if lvl < 4 else None
+        out = (cat[lvl][0] if split[lvl] else cat[lvl][..., :f[lvl]]) if lvl < 4 else None
         # the level's output goes into the decoder's concat buffer and, max-pooled by the same kernel, to the next level
         pooled = torch.empty(N, D >> (lvl + 1), H >> (lvl + 1), W >> (lvl + 1), f[lvl], dtype=T, device=dev) if lvl < 4 else None
         a1, s1 = c1.fwd(a0, out, pooled=pooled)
@@ -187,8 +193,14 @@ def _forward_cl(net: "UNet", x, keep: bool):
     for j, (up, c0, c1) in enumerate(net._dec):
         lvl = 3 - j
         up_in = cur
-        up.fwd(up_in, cat[lvl][..., f[lvl]:])
-        a0, s0 = c0.fwd(cat[lvl])
+        if split[lvl]:
+            up.fwd(up_in, cat[lvl][1])
+            y0, st0 = c0.conv.fwd_split(cat[lvl][0], cat[lvl][1])
+            a0, st0 = c0.norm.fwd(y0, stats=st0)
+            s0 = None
+        else:
+            up.fwd(up_in, cat[lvl][..., f[lvl]:])
+            a0, s0 = c0.fwd(cat[lvl])
         if lvl == 0:
             # last unit: only its raw conv output + statistics; the head normalises on load (no activation tensor)
             y1, st1 = c1.conv.fwd(a0, want_stats=True)

@@ -426,3 +426,29 @@ def test_sliding_window_sharded_two_ranks_equals_single_rank():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "SHARD_CHECK_OK" in r.stdout
+
+
+def test_unet_inference_split_concat_equals_concat_buffer(monkeypatch):
+    """UNet.infer_cl (the sliding-window forward) with the decoder's 64 -> 32 convs at the 96^3 / 48^3 levels as two
+    ping-pong launches (no concat buffer) against the concat-buffer form (MSSEG_NO_SPLIT_CAT=1): bf16 logits agree to the
+    extra rounding of one intermediate sum per such layer; the fp32 parity path never splits."""
+    from medicalsemseg_amd import hip
+    _, net = _unet_pair(torch.bfloat16)
+    g = torch.Generator().manual_seed(3)
+    win = torch.randn(2, 96, 96, 96, 1, generator=g).to(DEV).to(torch.bfloat16)
+    hip.TIMER.records.clear()
+    hip.TIMER.enabled = True
+    try:
+        a = net.infer_cl(win)[..., :3].float()
+        torch.cuda.synchronize()
+    finally:
+        hip.TIMER.enabled = False
+    n_v0 = hip.TIMER.summary().get("conv3d_k3_fwd/v0", {}).get("launches", 0)
+    hip.TIMER.records.clear()
+    assert n_v0 == 0                       # no 64-input-channel launch on the generic 4x8x16 kernel any more
+    monkeypatch.setenv("MSSEG_NO_SPLIT_CAT", "1")
+    b = net.infer_cl(win)[..., :3].float()
+    d = float((a - b).abs().max()) / float(b.abs().max())
+    agree = float((a.argmax(-1) == b.argmax(-1)).float().mean())
+    print(f"infer_cl split-concat vs concat buffer: max diff / scale {d:.2e}, arg-max agreement {agree:.4f}")
+    assert d < 2e-2 and agree > 0.99
