@@ -70,6 +70,8 @@ WORK = {
 KERNEL_NAMES = {
     "conv3d_k3_fwd/v3": ("k3pp_kernel (conv3d k3 fwd + dgrad, bf16, 32-input-channel stages, 4x4x16 tiles, LDS-DMA ping-pong)",
                          ("k3pp_kernel",)),
+    "conv3d_k3_fwd/v4": ("k3c48_kernel (conv3d k3 fwd + dgrad, bf16, 48 input channels per launch, 16-wide cout blocks, ping-pong)",
+                         ("k3c48_kernel",)),
     "conv3d_k3_fwd/v0": ("igemm_fwd_kernel<27,DIRECT,STORE,4,8,16,8> (conv3d k3 fwd + dgrad, 4x8x16 tiles)", ("igemm_fwd_kernel<27,4x8x16>",)),
     "conv3d_k3_fwd/v1": ("igemm_fwd_kernel<27,DIRECT,STORE,4,4,8,4> (conv3d k3 fwd + dgrad, 4x4x8 tiles)", ("igemm_fwd_kernel<27,4x4x8>",)),
     "conv3d_k3_fwd/v2": ("igemm_fwd_kernel<27,DIRECT,STORE,2,4,8,4> (conv3d k3 fwd + dgrad, 2x4x8 tiles)", ("igemm_fwd_kernel<27,2x4x8>",)),

@@ -82,7 +82,10 @@ int msseg_conv3d_k3_cout_block(int N, int D, int H, int W, int Cout);
 int msseg_conv3d_k3_variant(int N, int D, int H, int W, int Cout);
 /* kernel msseg_conv3d_k3_fwd / _dgrad_inbwd will run for this problem (16-byte aligned, dense operands):
  * 0/1/2 = generic implicit-GEMM tile configurations (as msseg_conv3d_k3_variant), 3 = the LDS-DMA ping-pong kernel
- * (bf16, 32 input channels per stage, large grids).  For per-kernel timing and reporting only. */
+ * (bf16, 32 input channels per stage, large grids), 4 = the 48-input-channel ping-pong kernel (bf16, Cin == 48,
+ * Cout % 16 == 0, N <= 4, large grids: Swin-UNETR's 48-wide UnetResBlock convolutions, models/segmentors/swin_unetr.py:
+ * 73-128).  Variant 4 reads a DIFFERENT weight image -- four msseg_pack_weights images back to back, see
+ * medicalsemseg_amd/hip.py pack_conv_k3_c48 and csrc/conv3d_k3_c48.hip -- so the packer must ask this function. */
 int msseg_conv3d_k3_kernel(int N, int D, int H, int W, int Cin, int Cout, int dtype);
 
 /* ---------------------------------------------------------------------------------------------
@@ -102,7 +105,9 @@ int msseg_conv3d_k3_fwd(const void* x, long long ldx, const void* wp, const floa
 /* y += conv3d k3 (x, w) without bias: the stored bf16 values of y are read back and the sums stored; stats = InstanceNorm
  * statistics of the sums.  Lets a 64-input-channel layer over cat([a, b]) run as two 32-channel launches on the ping-pong
  * kernel without a concat buffer (inference forward of MONAI BasicUNet's UpCat convs).  Only for shapes the
- * ping-pong kernel takes (bf16, Cin == 32, Cout % 32 == 0, large grids: msseg_conv3d_k3_kernel() == 3). */
+ * ping-pong kernel takes (bf16, Cin == 32, Cout % 32 == 0, large grids: msseg_conv3d_k3_kernel() == 3), and with
+ * Cin == 48 for the shapes of the 48-channel kernel (== 4): a 96-input-channel layer over cat([up, skip]) as two launches
+ * on the channel halves of the concat buffer (ldx = 96), Swin-UNETR's decoder blocks. */
 int msseg_conv3d_k3_fwd_accumulate(const void* x, long long ldx, const void* wp, void* y, long long ldy, int N, int D, int H,
                                    int W, int Cin, int Cout, float* stats, void* scratch, size_t scratch_bytes, int dtype,
                                    msseg_stream_t stream);

@@ -860,6 +860,7 @@ int msseg_conv3d_k3_variant(int N, int D, int H, int W, int Cout) {
 
 int msseg_conv3d_k3_kernel(int N, int D, int H, int W, int Cin, int Cout, int dtype) {
     int cfg, cb;
+    if (dtype == MSSEG_BF16 && Cin == 48 && msseg_k3c48_shape_ok(N, D, H, W, Cout)) return 4;
     k3_plan(N, D, H, W, Cout, &cfg, &cb);
     if (dtype == MSSEG_BF16 && cb == 32) {
         K3ppParams pp{};
@@ -896,6 +897,12 @@ int msseg_conv3d_k3_fwd_accumulate(const void* x, long long ldx, const void* wp,
     pp.stats = stats; pp.counter = (unsigned int*)scratch;
     pp.stats_ws = (float*)((unsigned char*)scratch + MSSEG_SCRATCH_COUNTER_BYTES);
     pp.accumulate = 1;
+    if (Cin == 48) {
+        if (!msseg_k3c48_eligible(pp))
+            MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_fwd_accumulate: 48 input channels need a shape and operands the 48-channel "
+                                     "kernel takes (msseg_conv3d_k3_kernel() == 4, 16-byte aligned x, N <= 4)");
+        return msseg_k3c48_launch(pp, (hipStream_t)stream);
+    }
     if (!msseg_k3pp_eligible(pp))
         MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_fwd_accumulate: only shapes of the ping-pong kernel (32 input channels, Cout %% 32 == 0, "
                                  "large grids; msseg_conv3d_k3_kernel() == 3)");
@@ -952,6 +959,13 @@ static int k3_fwd_impl(const void* x, long long ldx, const void* wp, const float
         pp.nb_y = p.nb_y; pp.nb_ldy = p.nb_ldy; pp.nb_a = p.nb_a; pp.nb_lda = p.nb_lda; pp.nb_stats = p.nb_stats;
         pp.nb_slope = p.nb_slope; pp.nb_eps = p.nb_eps; pp.nb_S = p.nb_S;
         pp.nb_dgamma = p.nb_dgamma; pp.nb_dbeta = p.nb_dbeta; pp.nb_acc = p.nb_acc;
+        if (Cin == 48 && msseg_k3c48_shape_ok(N, D, H, W, Cout)) {
+            // the packed image is the four-part one of the 48-channel kernel (msseg_conv3d_k3_kernel() == 4): no fallback
+            if (!msseg_k3c48_eligible(pp))
+                MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3: 48-input-channel layer on a large grid needs 16-byte aligned x, 8-byte "
+                                         "aligned y and ldx <= 256");
+            return msseg_k3c48_launch(pp, (hipStream_t)stream);
+        }
         int cfg, cb;
         k3_plan(N, D, H, W, Cout, &cfg, &cb);   // the packed weight image must be the 32-wide one
         if (cb == 32 && msseg_k3pp_eligible(pp)) return msseg_k3pp_launch(pp, (hipStream_t)stream);

@@ -26,6 +26,11 @@ struct K3ppParams {
 bool msseg_k3pp_eligible(const K3ppParams& p);
 int msseg_k3pp_launch(const K3ppParams& p, hipStream_t stream);
 
+// ---- 48 input channels per launch, 16-wide cout blocks (conv3d_k3_c48.hip); weight image = hip.pack_conv_k3_c48 ----
+bool msseg_k3c48_shape_ok(int N, int D, int H, int W, int M);   // grid / channel conditions (what the packer must know)
+bool msseg_k3c48_eligible(const K3ppParams& p);                 // ... and operand alignment
+int msseg_k3c48_launch(const K3ppParams& p, hipStream_t stream);
+
 // ---- second step of the fused conv-epilogue reductions (igemm_fwd.hip): one small block per cout block adds the
 // per-workgroup partial rows ws[(y * R + x) * L ..] in a fixed order and writes the per-(n, channel) results.  A
 // separate launch: the kernel boundary makes the partial rows visible without release/acquire fences (which would

@@ -245,12 +245,11 @@ class PackJob(C.Structure):
 
 # the most recent pack_weights call as a (src, dst, PackJob) triple: layers.PackedCache registers it for the
 # once-per-step batched refresh
-LAST_PACK_JOB = None
+LAST_PACK_JOBS = []     # (src, dst, PackJob) of every image packed since a PackedCache last cleared the list
 
 
 def pack_weights(src: torch.Tensor, dtype: torch.dtype, M, M0, T, K, K0, s_m1, s_m0, s_t, s_k1, s_k0, flip=False,
                  out: Optional[torch.Tensor] = None, cb: Optional[int] = None) -> torch.Tensor:
-    global LAST_PACK_JOB
     _need_gpu(src)
     assert src.dtype == torch.float32      # any layout the explicit strides describe (a channel slice of a conv weight)
     cb = cb or cout_block(M)
@@ -261,8 +260,8 @@ def pack_weights(src: torch.Tensor, dtype: torch.dtype, M, M0, T, K, K0, s_m1, s
     assert out.numel() * esz == nbytes
     _ck(lib().msseg_pack_weights(_p(src), _p(out), _DT[dtype], M, M0, T, K, K0, s_m1, s_m0, s_t, s_k1, s_k0,
                                  int(flip), cb, _stream()), "pack_weights")
-    LAST_PACK_JOB = (src, out, PackJob(_p(src), _p(out), s_m1, s_m0, s_t, s_k1, s_k0, nbytes // esz, M, M0, T, K, K0,
-                                       int(flip), cb, -(-K // (64 // esz))))
+    LAST_PACK_JOBS.append((src, out, PackJob(_p(src), _p(out), s_m1, s_m0, s_t, s_k1, s_k0, nbytes // esz, M, M0, T, K, K0,
+                                             int(flip), cb, -(-K // (64 // esz)))))
     return out
 
 
@@ -276,6 +275,9 @@ def pack_conv_k3(w: torch.Tensor, dtype, dgrad=False, out=None, vol=None, cb=Non
     Forward image W[co][tap][ci]; dgrad image W'[ci][26-tap][co].
     vol = (N, D, H, W) of the stride-1 problem the image will be used for (selects the cout block), or cb = the block."""
     co, ci = w.shape[0], w.shape[1]
+    if cb is None and vol is not None and out is None and dtype == torch.bfloat16 and (co if dgrad else ci) == 48 \
+            and lib().msseg_conv3d_k3_kernel(*vol, 48, ci if dgrad else co, BF16) == 4:
+        return pack_conv_k3_c48(w, dgrad)
     if not dgrad:
         cb = cb or (conv_k3_cout_block(*vol, co) if vol is not None else None)
         assert w.stride(1) == 27 and w.stride(4) == 1 and w.stride(0) % 27 == 0
@@ -283,6 +285,42 @@ def pack_conv_k3(w: torch.Tensor, dtype, dgrad=False, out=None, vol=None, cb=Non
     assert w.is_contiguous()
     cb = cb or (conv_k3_cout_block(*vol, ci) if vol is not None else None)
     return pack_weights(w, dtype, ci, ci, 27, co, co, 0, 27, 1, 0, ci * 27, True, out, cb)
+
+
+def pack_conv_k3_c48(w: torch.Tensor, dgrad=False):
+    """bf16 image of the 48-input-channel ping-pong kernel (csrc/conv3d_k3_c48.hip; msseg_conv3d_k3_kernel() == 4) for the
+    layer y = conv(x[48 ch], w) -- w: [Cout, 48, 3,3,3] (dense, or an input-channel slice of a dense weight) -- or, dgrad,
+    for dx = conv(dy[48 ch], w') of a layer w: [48, Cin, 3,3,3].  Four msseg_pack_weights images back to back, 16-wide cout
+    blocks: channels 0..31 of the 27 taps; channels 32..47 of the tap pairs (kw 0, kw 1) per (kd, kh); of (kd 0, kd 1)
+    at kw 2 per kh; of (kd 2, kw 2) per kh (upper half of the k-step zero)."""
+    co, ci = w.shape[0], w.shape[1]
+    n_el = w.untyped_storage().nbytes() // 4 - w.storage_offset()
+    flat = w.as_strided((n_el,), (1,))                            # the storage from w's first element on
+    if not dgrad:
+        assert ci == 48 and w.stride(1) == 27 and w.stride(4) == 1 and w.stride(0) % 27 == 0
+        M, s_m, s_c = co, w.stride(0), 27                         # strides of the output / input channel index
+    else:
+        assert co == 48 and w.is_contiguous()
+        M, s_m, s_c = ci, 27, ci * 27
+    assert M % 16 == 0
+    ncb = M // 16
+    buf = torch.empty(ncb * 42 * 512, dtype=torch.bfloat16, device=w.device)
+    o = [0, ncb * 27 * 512, ncb * 36 * 512, ncb * 39 * 512, ncb * 42 * 512]
+    rest = 32 * s_c
+    bf = torch.bfloat16
+    pack_weights(flat, bf, M, M, 27, 32, 32, 0, s_m, 1, 0, s_c, dgrad, buf[o[0]:o[1]], 16)
+    if not dgrad:
+        # T index = kd * 3 + kh (x 3 taps); k = [16 channels of tap A | 16 channels of tap B]
+        pack_weights(flat[rest:], bf, M, M, 9, 32, 16, 0, s_m, 3, 1, s_c, False, buf[o[1]:o[2]], 16)       # B = kw + 1
+        pack_weights(flat[rest + 2:], bf, M, M, 3, 32, 16, 0, s_m, 3, 9, s_c, False, buf[o[2]:o[3]], 16)   # kw 2: B = kd + 1
+        pack_weights(flat[rest + 20:], bf, M, M, 3, 16, 16, 0, s_m, 3, 0, s_c, False, buf[o[3]:o[4]], 16)  # (kd 2, kw 2)
+    else:
+        # the image's tap (kd, kh, kw) is the layer's tap (2-kd, 2-kh, 2-kw): the packer's flip reverses the T index, the
+        # base offset is the flipped kw / kd of tap A and tap B lies one tap / one plane BEFORE it
+        pack_weights(flat[rest + 2:], bf, M, M, 9, 32, 16, 0, s_m, 3, -1, s_c, True, buf[o[1]:o[2]], 16)
+        pack_weights(flat[rest + 18:], bf, M, M, 3, 32, 16, 0, s_m, 3, -9, s_c, True, buf[o[2]:o[3]], 16)
+        pack_weights(flat[rest:], bf, M, M, 3, 16, 16, 0, s_m, 3, 0, s_c, True, buf[o[3]:o[4]], 16)
+    return buf
 
 
 def pack_conv_k1(w: torch.Tensor, dtype, dgrad=False, out=None):
@@ -436,7 +474,7 @@ def conv3d_k3_accumulate(x, wp, y, cin, cout, stats):
     N, D, H, W = x.shape[:4]
     nv = N * D * H * W
     sc = scratch(x.device)
-    TIMER.launch("conv3d_k3_fwd/v3", 2.0 * nv * 27 * cin * cout, nv * (cin + 2 * cout) * x.element_size() + 27 * cin * cout * 2,
+    TIMER.launch("conv3d_k3_fwd/v%d" % (4 if cin == 48 else 3), 2.0 * nv * 27 * cin * cout, nv * (cin + 2 * cout) * x.element_size() + 27 * cin * cout * 2,
                  lambda: _ck(lib().msseg_conv3d_k3_fwd_accumulate(_p(x), ld(x), _p(wp), _p(y), ld(y), N, D, H, W, cin, cout,
                                                                  _p(stats), _p(sc), sc.numel(), dt(x), _stream()),
                              "conv3d_k3_fwd_accumulate"))

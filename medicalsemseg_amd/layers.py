@@ -96,7 +96,8 @@ class PackedCache:
     def __del__(self):
         try:
             for (dtype, _), rec in self._val.items():
-                PACK_REGISTRY.drop(rec["src"].device, dtype, rec)
+                for r in [rec] + rec.get("extra", []):
+                    PACK_REGISTRY.drop(r["src"].device, dtype, r)
         except Exception:   # interpreter shutdown
             pass
 
@@ -104,19 +105,22 @@ class PackedCache:
         k = (dtype, kind)
         rec = self._val.get(k)
         if rec is not None and (rec["src"].data_ptr() != p.data_ptr() or rec["src"].device != p.device):
-            PACK_REGISTRY.drop(rec["src"].device, dtype, rec)   # the parameter moved: rebuild from scratch
+            for r in [rec] + rec.get("extra", []):
+                PACK_REGISTRY.drop(r["src"].device, dtype, r)   # the parameter moved: rebuild from scratch
             rec = None
         if rec is None:
-            hip.LAST_PACK_JOB = None
+            hip.LAST_PACK_JOBS.clear()
             v = builder()
-            src, dst, job = hip.LAST_PACK_JOB
-            assert dst.data_ptr() == v.data_ptr()
-            rec = PACK_REGISTRY.add(p.device, dtype, src, dst, job)
+            jobs = list(hip.LAST_PACK_JOBS)     # one image, or the sub-images of a composite one (pack_conv_k3_c48)
+            assert jobs and jobs[0][1].data_ptr() == v.data_ptr()
+            recs = [PACK_REGISTRY.add(p.device, dtype, src, dst, job) for src, dst, job in jobs]
+            rec = recs[0]
+            rec["extra"], rec["value"] = recs[1:], v
             self._val[k] = rec
             return v
         if rec["state"] != (rec["src"]._version, weights_epoch):
             PACK_REGISTRY.refresh(p.device, dtype)
-        return rec["dst"]
+        return rec["value"]
 
 
 class _WgradSide:
@@ -243,6 +247,8 @@ class Conv3:
         """returns y, or (y, stats) when want_stats: InstanceNorm statistics of y, fused into the conv epilogue
         where the kernel supports it, otherwise one extra pass."""
         dtype = x.dtype
+        if want_stats and out is None and self.halves_ok(tuple(x.shape[:4]), dtype):
+            return self.fwd_halves(x)
         y = out if out is not None else _empty_like_vol(x, self.cout)
         stats = None
         if self._gather(dtype):
@@ -263,6 +269,26 @@ class Conv3:
         if want_stats:
             return y, (stats if stats is not None else hip.channel_stats(y))
         return y
+
+    def halves_ok(self, vol, dtype) -> bool:
+        """96 input channels on a grid the 48-channel ping-pong kernel takes (Swin-UNETR's decoder convs over cat(up, skip))"""
+        return (self.cin == 96 and dtype == torch.bfloat16 and not os.environ.get("MSSEG_NO_SPLIT_CAT")
+                and hip.lib().msseg_conv3d_k3_kernel(*vol, 48, self.cout, hip.BF16) == 4)
+
+    def fwd_halves(self, x):
+        """y = conv(x[96 ch]) + bias as two launches of the 48-channel kernel on the two channel halves of x (the concat
+        buffer): the second adds its sums onto the stored result of the first and emits the InstanceNorm statistics.  The
+        generic kernel pads 96 -> 48 to 3 x 32 input and 2 x 32 output channels and runs one stage after the other; the
+        intermediate sum is rounded to bf16 once more than there.  Returns (y, stats)."""
+        dtype, vol = x.dtype, tuple(x.shape[:4])
+        wa, wb = self.w.detach()[:, :48], self.w.detach()[:, 48:]
+        pa = self.cache.get(wa, dtype, ("fa48", vol), lambda: hip.pack_conv_k3(wa, dtype, vol=vol))
+        pb = self.cache.get(wb, dtype, ("fb48", vol), lambda: hip.pack_conv_k3(wb, dtype, vol=vol))
+        y = _empty_like_vol(x, self.cout)
+        hip.conv3d_k3(x[..., :48], pa, self.b, y, 48, self.cout)
+        stats = torch.empty(x.shape[0], self.cout, 2, dtype=torch.float32, device=x.device)
+        hip.conv3d_k3_accumulate(x[..., 48:], pb, y, 48, self.cout, stats)
+        return y, stats
 
     def split_ok(self, vol, dtype, ca, cb_) -> bool:
         """can conv(cat([a, b])) with a: ca, b: cb_ channels on the grid vol = (N, D, H, W) run as two launches of the

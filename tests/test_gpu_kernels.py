@@ -75,6 +75,10 @@ def test_conv3d_k3_fwd_dgrad_wgrad(dtype, cin, cout, sp):
     xg = cl(x, dtype, dev)
     y = op.fwd(xg)
     check(ncdhw(y), yref.detach(), dtype, "conv3d_k3 fwd")
+    if dtype == torch.bfloat16 and sp in ((32, 32, 64), (30, 33, 36)):
+        # the 48-channel ping-pong kernel takes the 48-input-channel launches of these two layers: forward of 48 -> 48,
+        # input gradient of both (48 gradient channels in)
+        assert hip.lib().msseg_conv3d_k3_kernel(N, *sp, 48, cin, hip.BF16) == 4
     dyg = cl(dy, dtype, dev)
     dx = op.bwd(xg, dyg, True)
     check(ncdhw(dx), xr.grad, dtype, "conv3d_k3 dgrad")
@@ -83,6 +87,31 @@ def test_conv3d_k3_fwd_dgrad_wgrad(dtype, cin, cout, sp):
     # accumulate path
     op.bwd(xg, dyg, False)
     check(wp.grad, 2 * wr.grad, dtype, "conv3d_k3 wgrad accumulate")
+
+
+@pytest.mark.parametrize("sp,N", [((32, 32, 64), 2), ((30, 33, 36), 3)])
+def test_conv3d_k3_96_channels_as_two_48_channel_launches(sp, N):
+    """Conv3.fwd(want_stats) of a 96 -> 48 layer over a concat buffer (Swin-UNETR decoder, swin_unetr.py:73-128 of the
+    reference) = two launches of the 48-channel kernel on the buffer's channel halves, the second accumulating onto the
+    first's stored result and emitting the InstanceNorm statistics"""
+    from medicalsemseg_amd import hip
+    from medicalsemseg_amd.layers import Conv3
+    dev, dtype = _dev(), torch.bfloat16
+    x = gen(N, 96, *sp, seed=1)
+    w = gen(48, 96, 3, 3, 3, seed=2, scale=(96 * 27) ** -0.5)
+    b = gen(48, seed=3)
+    xr, wr = rnd(dtype, x, w)
+    yref = F.conv3d(xr, wr, b, padding=1)
+    op = Conv3(torch.nn.Parameter(w.to(dev)), torch.nn.Parameter(b.to(dev)))
+    xg = cl(x, dtype, dev)
+    assert op.halves_ok((N, *sp), dtype)
+    y, stats = op.fwd(xg, want_stats=True)
+    check(ncdhw(y), yref, dtype, "conv 96 -> 48 as two halves")
+    yf = y.float().reshape(N, -1, 48)
+    ref = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)
+    assert float((stats - ref).abs().max()) / float(ref.abs().max()) < 1e-5
+    y2, stats2 = op.fwd(xg, want_stats=True)
+    assert torch.equal(y2, y) and torch.equal(stats2, stats)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -395,7 +424,9 @@ def test_unet_small_fwd_bwd(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,sp,N", [(32, 32, (32, 32, 32), 2), (32, 64, (12, 12, 12), 3), (16, 48, (6, 6, 6), 1),
-                                           (32, 32, (32, 48, 64), 2), (32, 64, (30, 29, 38), 3)])
+                                           (32, 32, (32, 48, 64), 2), (32, 64, (30, 29, 38), 3),
+                                           # 48 input channels: the 16-wide-cout-block ping-pong kernel (bf16)
+                                           (48, 48, (32, 32, 64), 2), (48, 96, (30, 33, 36), 3), (48, 16, (40, 40, 40), 4)])
 def test_conv3d_k3_fused_stats(dtype, cin, cout, sp, N):
     """InstanceNorm statistics from the conv epilogue == statistics of the stored output (separate pass + torch)"""
     from medicalsemseg_amd import hip
@@ -426,11 +457,13 @@ def test_batched_weight_packing_equals_single_packing():
     from medicalsemseg_amd import hip, layers
     dev = _dev()
     ws = [torch.nn.Parameter(gen(*shape, seed=i).to(dev)) for i, shape in
-          enumerate([(32, 32, 3, 3, 3), (64, 32, 3, 3, 3), (48, 96, 3, 3, 3), (3, 32, 1, 1, 1), (32, 1, 3, 3, 3)])]
+          enumerate([(32, 32, 3, 3, 3), (64, 32, 3, 3, 3), (48, 96, 3, 3, 3), (3, 32, 1, 1, 1), (32, 1, 3, 3, 3),
+                     (48, 48, 3, 3, 3)])]     # the last one: the four-part image of the 48-channel kernel (bf16)
     for dtype in DTYPES:
         caches = [layers.PackedCache() for _ in ws]
         builders = [lambda w=w: hip.pack_conv_k3(w.detach(), dtype, vol=(2, 32, 32, 32)) for w in ws[:3]]
         builders += [lambda w=ws[3]: hip.pack_conv_k1(w.detach().reshape(3, 32), dtype), lambda w=ws[4]: hip.pack_conv_gather(w.detach(), dtype)]
+        builders += [lambda w=ws[5]: hip.pack_conv_k3(w.detach(), dtype, vol=(2, 32, 32, 64))]
         first = [c.get(w, dtype, "f", b).clone() for c, w, b in zip(caches, ws, builders)]
         with torch.no_grad():
             for w in ws:
@@ -449,6 +482,11 @@ def test_conv3d_k3_kernel_choice():
     assert L.msseg_conv3d_k3_kernel(2, 96, 96, 96, 32, 32, hip.F32) == 0       # fp32: generic big tile
     assert L.msseg_conv3d_k3_kernel(2, 96, 96, 96, 64, 32, hip.BF16) == 0      # two channel blocks per stage
     assert L.msseg_conv3d_k3_kernel(2, 12, 12, 12, 32, 32, hip.BF16) in (1, 2)  # small grid
+    assert L.msseg_conv3d_k3_kernel(2, 96, 96, 96, 48, 48, hip.BF16) == 4      # 48 input channels: 16-wide-block ping-pong
+    assert L.msseg_conv3d_k3_kernel(2, 48, 48, 48, 48, 96, hip.BF16) == 4
+    assert L.msseg_conv3d_k3_kernel(2, 96, 96, 96, 48, 48, hip.F32) == 0
+    assert L.msseg_conv3d_k3_kernel(8, 96, 96, 96, 48, 48, hip.BF16) == 0      # more samples than its statistics slots
+    assert L.msseg_conv3d_k3_kernel(2, 12, 12, 12, 48, 48, hip.BF16) in (1, 2)
 
 
 def test_flat_adamw_matches_torch_adamw():
@@ -481,7 +519,9 @@ def test_flat_adamw_matches_torch_adamw():
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,sp,N", [(32, 32, (32, 32, 32), 2), (64, 32, (12, 12, 12), 2), (16, 48, (6, 6, 6), 1),
-                                           (32, 32, (32, 48, 64), 2), (64, 32, (30, 29, 38), 3)])
+                                           (32, 32, (32, 48, 64), 2), (64, 32, (30, 29, 38), 3),
+                                           # 48 gradient channels in: the 48-channel ping-pong kernel (bf16)
+                                           (48, 48, (32, 32, 64), 2), (96, 48, (30, 33, 36), 2)])
 def test_conv_dgrad_fused_instnorm_backward_reductions(dtype, cin, cout, sp, N):
     """da = dgrad(dy) with the InstanceNorm-backward reductions of the receiving layer fused in the epilogue ==
     separate dgrad + msseg_instnorm_act_bwd_reduce"""
