@@ -404,6 +404,17 @@ int msseg_layernorm_param_grad(const void* x, long long ldx, const float* mean, 
 /* exact (erf) GELU */
 int msseg_gelu_fwd(const void* x, void* y, long long n, int dtype, msseg_stream_t stream);
 int msseg_gelu_bwd(const void* x, const void* dy, void* dx, long long n, int dtype, msseg_stream_t stream);
+/* Linear + GELU of a Swin block's MLP in one pass each way (models/backbones/swin_nnformer.py:24-42 of the reference: fc1,
+ * act, fc2; north_star "GELU fusion").  fwd: pre = x W^T + b and act = gelu(pre as stored) from ONE launch (the separate
+ * GELU pass re-read pre).  bwd: dpre = (dy W2) * gelu'(pre) -- fc2's input gradient written as fc1's output gradient (the
+ * separate pass wrote and re-read the intermediate).  Bit-identical to msseg_conv3d_k1_fwd + msseg_gelu_fwd / _bwd.
+ * wp: msseg_pack_weights image (T = 1) of the layer (bwd: of fc2's input-gradient form).  bf16, the register-resident-weight
+ * kernel's shapes C -> 4C at C = 48, 96, 192, 384 (msseg_linear_gelu_ok() == 1); callers keep the two-kernel chain otherwise. */
+int msseg_linear_gelu_ok(long long NV, int Cin, int Cout, int dtype);
+int msseg_linear_gelu_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* pre, long long ldpre, void* act,
+                          long long ldact, long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
+int msseg_linear_gelu_bwd(const void* dy, long long lddy, const void* wp, const void* pre, long long ldpre, void* dpre,
+                          long long lddpre, long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dice + cross-entropy loss (MONAI DiceCELoss(to_onehot_y, softmax, squared_pred) as built at

@@ -14,6 +14,12 @@
 // wave-private LDS tile and writes the rows as coalesced 16-byte stores.  grid.y slices the output channels: workgroup
 // (x, s) computes channels s * NH * 16 .. of its tokens, so that a wide layer's weights still fit the register file and
 // a short token list still fills the chip.
+//
+// Fused epilogues for the MLP of a Swin block (fc1 -> GELU -> fc2, /root/reference/models/backbones/swin_nnformer.py:24-42),
+// applied to the 16-byte output chunks on their way from the LDS tile to memory:
+//   EPI_GELU      y = the pre-activation, y2 = gelu(y as stored): fc1 + GELU forward without the separate pass that re-reads it
+//   EPI_GELU_BWD  y = (dy W) as stored * gelu'(aux): the input gradient of fc2 straight into the gradient of fc1's output
+// with the arithmetic of gelu_kernel (attention.hip) on the bf16-rounded operands, i.e. bit-identical to the unfused chain.
 #include "k3pp.h"
 
 #include <stdlib.h>
@@ -29,7 +35,15 @@ struct LinParams {
     void* y; long long ldy;
     long long NV;
     int K, cb;                       // logical input channels, cout block width of the image
+    void* y2; long long ldy2;        // EPI_GELU: the activation
+    const void* aux; long long ldaux;   // EPI_GELU_BWD: the pre-activation of the layer that receives this gradient
 };
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GELU_BWD = 2 };
+
+MSSEG_DEVFN float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+MSSEG_DEVFN float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+MSSEG_DEVFN float gelu_cdf(float v) { return 0.5f * (1.f + erff(v * 0.70710678118654752f)); }
 
 MSSEG_DEVFN u32x4_t ldg16(const void* p) { return *(const u32x4_t*)p; }
 
@@ -39,7 +53,7 @@ MSSEG_DEVFN unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int KS, int NH>   // KS = ceil(K / 32) k-steps, NH = M / 16 output tiles
+template <int KS, int NH, int EPI>   // KS = ceil(K / 32) k-steps, NH = M / 16 output tiles
 __global__ __launch_bounds__(LR_THREADS, 2) void linear_regw_kernel(const LinParams p) {
     constexpr int M = NH * 16;
     constexpr int RSB = M * 2 + 16;                    // LDS bytes per token row (16-byte pad: fewer write conflicts)
@@ -96,21 +110,40 @@ __global__ __launch_bounds__(LR_THREADS, 2) void linear_regw_kernel(const LinPar
             const int ch = it * 64 + lane;
             const int vv = ch / CPV, part = ch - vv * CPV;
             if (ch < 16 * CPV && vv < nv) {
-                const u32x4_t o = *(const u32x4_t*)(tile + vv * RSB + part * 16);
+                u32x4_t o = *(const u32x4_t*)(tile + vv * RSB + part * 16);
+                if constexpr (EPI == EPI_GELU_BWD) {
+                    const u32x4_t a = *(const u32x4_t*)((const bf16_t*)p.aux + mbase + (v0 + vv) * p.ldaux + part * 8);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float a0 = bf16_lo(a[w]), a1 = bf16_hi(a[w]);
+                        const float g0 = bf16_lo(o[w]) * (gelu_cdf(a0) + a0 * 0.3989422804014327f * expf(-0.5f * a0 * a0));
+                        const float g1 = bf16_hi(o[w]) * (gelu_cdf(a1) + a1 * 0.3989422804014327f * expf(-0.5f * a1 * a1));
+                        o[w] = pack_bf16x2(g0, g1);
+                    }
+                }
                 *(u32x4_t*)(yg + (v0 + vv) * p.ldy + part * 8) = o;
+                if constexpr (EPI == EPI_GELU) {
+                    u32x4_t h;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float a0 = bf16_lo(o[w]), a1 = bf16_hi(o[w]);
+                        h[w] = pack_bf16x2(a0 * gelu_cdf(a0), a1 * gelu_cdf(a1));
+                    }
+                    *(u32x4_t*)((bf16_t*)p.y2 + mbase + (v0 + vv) * p.ldy2 + part * 8) = h;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next group's writes
     }
 }
 
-template <int KS, int NH> int launch(const LinParams& p, int slices, hipStream_t stream) {
+template <int KS, int NH, int EPI = EPI_NONE> int launch(const LinParams& p, int slices, hipStream_t stream) {
     const long long groups = (p.NV + 15) >> 4;
     long long gx = (groups + 3) / 4;
     long long cap = (long long)msseg_num_cus() * 2 / slices;
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL((linear_regw_kernel<KS, NH>), dim3((unsigned)gx, (unsigned)slices), dim3(LR_THREADS), 0, stream, p);
+    hipLaunchKernelGGL((linear_regw_kernel<KS, NH, EPI>), dim3((unsigned)gx, (unsigned)slices), dim3(LR_THREADS), 0, stream, p);
     MSSEG_CHECK_LAUNCH("linear_regw");
     return MSSEG_OK;
 }
@@ -174,3 +207,64 @@ int msseg_linear_regw_launch(const void* x, long long ldx, const void* wp, const
         default: return launch_ks<24>(p, nh, slices, stream);
     }
 }
+
+// ---- fused GELU epilogues: the (k-steps, output tiles) pairs of fc1 / fc2's input gradient at the Swin widths
+// (C -> 4C for C = 48, 96, 192, 384); everything else takes the unfused chain (msseg_linear_gelu_ok() == 0)
+static bool lr_gelu_shape(int Cin, int Cout, int* ks_out, int* nh_out) {
+    const int ks = (Cin + 31) / 32;
+    if (!lr_ks_ok(ks)) return false;
+    const int nh = pick_nh(ks, Cout);
+    const bool ok = (ks == 2 && nh == 12) || (ks == 3 && nh == 6) || (ks == 6 && nh == 4) || (ks == 12 && nh == 2);
+    if (ks_out) { *ks_out = ks; *nh_out = nh; }
+    return ok;
+}
+
+template <int EPI> static int launch_gelu(const LinParams& p, int ks, int nh, int Cout, hipStream_t stream) {
+    const int slices = Cout / (nh * 16);
+    if (ks == 2) return launch<2, 12, EPI>(p, slices, stream);
+    if (ks == 3) return launch<3, 6, EPI>(p, slices, stream);
+    if (ks == 6) return launch<6, 4, EPI>(p, slices, stream);
+    return launch<12, 2, EPI>(p, slices, stream);
+}
+
+extern "C" {
+
+int msseg_linear_gelu_ok(long long NV, int Cin, int Cout, int dtype) {
+    static const bool off = getenv("MSSEG_NO_LINEAR_GELU") != nullptr || getenv("MSSEG_NO_LINEAR_REGW") != nullptr;   // A/B switch
+    if (off || dtype != MSSEG_BF16 || NV < 1 || Cout % 16 || Cin % 8) return 0;
+    return lr_gelu_shape(Cin, Cout, nullptr, nullptr) ? 1 : 0;
+}
+
+static int lin_check(const void* x, long long ldx, const void* wp, const void* y, long long ldy, const void* z, long long ldz,
+                     const float* bias, long long NV, int Cin, int Cout, int dtype, const char* who) {
+    if (!x || !wp || !y || !z) MSSEG_FAIL(MSSEG_EINVAL, "%s: null pointer", who);
+    if (!msseg_linear_gelu_ok(NV, Cin, Cout, dtype)) MSSEG_FAIL(MSSEG_EINVAL, "%s: shape %d -> %d not supported (msseg_linear_gelu_ok)", who, Cin, Cout);
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)z & 15) || ((uintptr_t)wp & 15) || (ldx % 8) || (ldy % 8) || (ldz % 8) ||
+        ldx < Cin || ldy < Cout || ldz < Cout || (bias && ((uintptr_t)bias & 15)))
+        MSSEG_FAIL(MSSEG_EINVAL, "%s: operands must be 16-byte aligned with strides that are multiples of 8 elements", who);
+    return MSSEG_OK;
+}
+
+int msseg_linear_gelu_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* pre, long long ldpre, void* act,
+                          long long ldact, long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+    if (int rc = lin_check(x, ldx, wp, pre, ldpre, act, ldact, bias, NV, Cin, Cout, dtype, "linear_gelu_fwd")) return rc;
+    LinParams p{};
+    p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = pre; p.ldy = ldpre; p.y2 = act; p.ldy2 = ldact; p.NV = NV; p.K = Cin;
+    p.cb = msseg_cout_block(Cout);
+    int ks, nh;
+    lr_gelu_shape(Cin, Cout, &ks, &nh);
+    return launch_gelu<EPI_GELU>(p, ks, nh, Cout, (hipStream_t)stream);
+}
+
+int msseg_linear_gelu_bwd(const void* dy, long long lddy, const void* wp, const void* pre, long long ldpre, void* dpre,
+                          long long lddpre, long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+    if (int rc = lin_check(dy, lddy, wp, dpre, lddpre, pre, ldpre, nullptr, NV, Cin, Cout, dtype, "linear_gelu_bwd")) return rc;
+    LinParams p{};
+    p.x = dy; p.ldx = lddy; p.wp = wp; p.y = dpre; p.ldy = lddpre; p.aux = pre; p.ldaux = ldpre; p.NV = NV; p.K = Cin;
+    p.cb = msseg_cout_block(Cout);
+    int ks, nh;
+    lr_gelu_shape(Cin, Cout, &ks, &nh);
+    return launch_gelu<EPI_GELU_BWD>(p, ks, nh, Cout, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -69,6 +69,9 @@ SIGNATURES = {
     "msseg_layernorm_param_grad": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _i, _ll, _i, _vp, _sz, _i, _vp], _i),
     "msseg_gelu_fwd": ([_vp, _vp, _ll, _i, _vp], _i),
     "msseg_gelu_bwd": ([_vp, _vp, _vp, _ll, _i, _vp], _i),
+    "msseg_linear_gelu_ok": ([_ll, _i, _i, _i], _i),
+    "msseg_linear_gelu_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
+    "msseg_linear_gelu_bwd": ([_vp, _ll, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_stem_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_k1_head_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _ll, _i, _i, _vp, _ll, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                           _vp, _i, _vp, _sz, _i, _vp], _i),
@@ -1277,6 +1280,34 @@ def gelu_fwd(x, y):
     assert x.is_contiguous() and y.is_contiguous()
     _ck(lib().msseg_gelu_fwd(_p(x), _p(y), x.numel(), dt(x), _stream()), "gelu_fwd")
     return y
+
+
+def linear_gelu_ok(x, cin, cout) -> bool:
+    """fc1 + GELU (and fc2's input gradient + GELU backward) of a cin -> cout MLP on x's tokens run as one launch each"""
+    return bool(x.is_cuda and x.dtype == torch.bfloat16 and
+                lib().msseg_linear_gelu_ok(x.numel() // x.shape[-1], cin, cout, BF16))
+
+
+def linear_gelu_fwd(x, wp, bias, pre, act, cin, cout):
+    """pre = x W^T + b, act = gelu(pre) in one launch (bit-identical to conv3d_k1 + gelu_fwd)"""
+    _need_gpu(x, wp, pre, act)
+    nv = x.numel() // x.shape[-1]
+    esz = x.element_size()
+    TIMER.launch("linear_gelu_fwd", 2.0 * nv * cin * cout, nv * (cin + 2 * cout) * esz + cin * cout * esz,
+                 lambda: _ck(lib().msseg_linear_gelu_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(pre), ld(pre), _p(act), ld(act), nv,
+                                                         cin, cout, dt(x), _stream()), "linear_gelu_fwd"))
+    return pre, act
+
+
+def linear_gelu_bwd(dy, wp, pre, dpre, cin, cout):
+    """dpre = (dy W) * gelu'(pre): cin = channels of dy, cout = channels of pre / dpre (bit-identical to conv3d_k1 + gelu_bwd)"""
+    _need_gpu(dy, wp, pre, dpre)
+    nv = dy.numel() // dy.shape[-1]
+    esz = dy.element_size()
+    TIMER.launch("linear_gelu_bwd", 2.0 * nv * cin * cout, nv * (cin + 2 * cout) * esz + cin * cout * esz,
+                 lambda: _ck(lib().msseg_linear_gelu_bwd(_p(dy), ld(dy), _p(wp), _p(pre), ld(pre), _p(dpre), ld(dpre), nv, cin,
+                                                         cout, dt(dy), _stream()), "linear_gelu_bwd"))
+    return dpre
 
 
 def gelu_bwd(x, dy, dx):

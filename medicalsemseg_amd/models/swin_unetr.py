@@ -259,8 +259,7 @@ class _Block(nn.Module):
         if isinstance(self.mlp, (_DepthMlp, _InceptionMlp)):
             y = self.mlp.run(y)
         else:
-            y = ops.gelu(ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
-            y = ops.linear(y, self.mlp.fc2.weight, self.mlp.fc2.bias)
+            y = ops.mlp(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias)
         return ops.add(x, y, self._dp_scale(x))
 
 

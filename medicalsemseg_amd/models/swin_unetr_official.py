@@ -80,8 +80,7 @@ class _Block(nn.Module):
         y = ops.linear(y, a.proj.weight, a.proj.bias)   # per-token: commutes with the crop
         x = ops.add(x, y)
         y = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        y = ops.gelu(ops.linear(y, self.mlp.linear1.weight, self.mlp.linear1.bias))
-        y = ops.linear(y, self.mlp.linear2.weight, self.mlp.linear2.bias)
+        y = ops.mlp(y, self.mlp.linear1.weight, self.mlp.linear1.bias, self.mlp.linear2.weight, self.mlp.linear2.bias)
         return ops.add(x, y)
 
 

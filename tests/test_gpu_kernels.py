@@ -489,6 +489,40 @@ def test_conv3d_k3_kernel_choice():
     assert L.msseg_conv3d_k3_kernel(2, 12, 12, 12, 48, 48, hip.BF16) in (1, 2)
 
 
+@pytest.mark.parametrize("C,tokens", [(48, (2, 9, 11, 13)), (96, (1, 6, 7, 8)), (192, (1, 3, 5, 7)), (384, (1, 3, 3, 3)), (40, (1, 4, 5, 6))])
+def test_mlp_fused_gelu_equals_linear_gelu_linear(C, tokens):
+    """ops.mlp (GELU in the epilogues of fc1 and of fc2's input gradient, csrc/linear_regw.hip) == ops.linear -> ops.gelu ->
+    ops.linear, bit for bit: outputs, input gradient and all four parameter gradients (bf16; C = 40 is a shape the fused
+    kernel does not take: the autograd node then runs the three kernels itself)"""
+    from medicalsemseg_amd import hip, ops
+    dev, dtype = _dev(), torch.bfloat16
+    x0 = gen(*tokens, C, seed=1).to(dev).to(dtype)
+    dy = gen(*tokens, C, seed=2).to(dev).to(dtype)
+    mk = lambda *sh, seed, sc: torch.nn.Parameter((gen(*sh, seed=seed) * sc).to(dev))   # noqa: E731
+    ps = [mk(4 * C, C, seed=3, sc=C ** -0.5), mk(4 * C, seed=4, sc=0.5), mk(C, 4 * C, seed=5, sc=(4 * C) ** -0.5), mk(C, seed=6, sc=0.5)]
+    assert hip.linear_gelu_ok(x0, C, 4 * C) == (C != 40)
+    res = []
+    for fused in (True, False):
+        for q in ps:
+            q.grad = None
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            y = ops.mlp(x, *ps)
+        else:
+            y = ops.linear(ops.gelu(ops.linear(x, ps[0], ps[1])), ps[2], ps[3])
+        y.backward(dy)
+        res.append([y.detach().clone(), x.grad.clone()] + [q.grad.clone() for q in ps])
+    for a, b, nm in zip(res[0], res[1], ("y", "dx", "dW1", "db1", "dW2", "db2")):
+        assert torch.equal(a, b), f"{nm}: max diff {float((a.float() - b.float()).abs().max()):.3e}"
+    # and against torch in fp32 on the bf16-rounded operands
+    xr = x0.float().cpu().requires_grad_(True)
+    w1, b1, w2, b2 = [q.detach().cpu() for q in ps]
+    yr = F.linear(F.gelu(F.linear(xr, w1.to(dtype).float(), b1)), w2.to(dtype).float(), b2)
+    yr.backward(dy.float().cpu())
+    check(res[0][0], yr.detach(), dtype, "mlp y", scale=float(yr.detach().abs().max()))
+    check(res[0][1], xr.grad, dtype, "mlp dx", scale=float(xr.grad.abs().max()))
+
+
 def test_flat_adamw_matches_torch_adamw():
     """fused flat-buffer AdamW (+ weight-decay grouping, + folded gradient clipping) vs torch.optim.AdamW"""
     from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay
