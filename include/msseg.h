@@ -213,6 +213,15 @@ int msseg_conv3d_k3_wgrad(const void* x, long long ldx, const void* dy, long lon
 int msseg_conv3d_k1_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw,
                           long long NV, int Cin, int Cout, int accumulate,
                           void* workspace, size_t workspace_bytes, int dtype, msseg_stream_t stream);
+/* Weight AND bias gradient of nn.Linear / a 1x1x1 convolution in one pass over the tokens: dw[Cout][Cin] (+)= dy^T x,
+ * dbias[Cout] (+)= column sums of dy (dbias nullable).  Replaces autograd's two reductions for the Swin stages' Linear layers
+ * (models/backbones/swin_nnformer.py:24-42,128-196).  bf16; channel counts that split into the kernel's output slices
+ * (msseg_linear_wgrad_ok() == 1: multiples of 48 on both sides cover every Swin width); deterministic; workspace as
+ * msseg_wgrad_workspace_bytes(Cout, 1, Cin).  Callers keep msseg_conv3d_k1_wgrad + msseg_channel_sum otherwise. */
+int msseg_linear_wgrad_ok(long long NV, int Cin, int Cout, int dtype);
+int msseg_linear_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, float* dbias, long long NV,
+                       int Cin, int Cout, int accumulate_w, int accumulate_b, void* workspace, size_t workspace_bytes,
+                       int dtype, msseg_stream_t stream);
 int msseg_conv3d_gather_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw,
                               int N, int ID, int IH, int IW, int Cin, int Cout, int k, int s, int p, int accumulate,
                               void* workspace, size_t workspace_bytes, int dtype, msseg_stream_t stream);

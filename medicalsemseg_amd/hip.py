@@ -69,6 +69,8 @@ SIGNATURES = {
     "msseg_layernorm_param_grad": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _i, _ll, _i, _vp, _sz, _i, _vp], _i),
     "msseg_gelu_fwd": ([_vp, _vp, _ll, _i, _vp], _i),
     "msseg_gelu_bwd": ([_vp, _vp, _vp, _ll, _i, _vp], _i),
+    "msseg_linear_wgrad_ok": ([_ll, _i, _i, _i], _i),
+    "msseg_linear_wgrad": ([_vp, _ll, _vp, _ll, _vp, _vp, _ll, _i, _i, _i, _i, _vp, _sz, _i, _vp], _i),
     "msseg_linear_gelu_ok": ([_ll, _i, _i, _i], _i),
     "msseg_linear_gelu_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_linear_gelu_bwd": ([_vp, _ll, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
@@ -757,6 +759,23 @@ def conv3d_k1_wgrad(x, dy, dw, cin, cout, accumulate=False):
     ws = _wg_ws(cout, 1, cin, x.device)
     _ck(lib().msseg_conv3d_k1_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), nv, cin, cout, int(accumulate), _p(ws),
                                     ws.numel(), dt(x), _stream()), "conv3d_k1_wgrad")
+
+
+def linear_wgrad_ok(x, cin, cout) -> bool:
+    return bool(x.is_cuda and x.dtype == torch.bfloat16 and
+                lib().msseg_linear_wgrad_ok(x.numel() // x.shape[-1], cin, cout, BF16))
+
+
+def linear_wgrad(x, dy, dw, dbias, cin, cout, accumulate_w=False, accumulate_b=False):
+    """dw[cout][cin] (+)= dy^T x and dbias[cout] (+)= dy.sum(tokens) (dbias None: weight only) in one pass over the tokens"""
+    _need_gpu(x, dy, dw)
+    nv = x.numel() // x.shape[-1]
+    ws = _wg_ws(cout, 1, cin, x.device)
+    esz = x.element_size()
+    TIMER.launch("linear_wgrad", 2.0 * nv * cin * cout, nv * (cin + cout) * esz + cin * cout * 4,
+                 lambda: _ck(lib().msseg_linear_wgrad(_p(x), ld(x), _p(dy), ld(dy), _p(dw), _p(dbias), nv, cin, cout,
+                                                      int(accumulate_w), int(accumulate_b), _p(ws), ws.numel(), dt(x),
+                                                      _stream()), "linear_wgrad"))
 
 
 def conv3d_gather_wgrad(x, dy, dw, cin, cout, k, s, p, accumulate=False):

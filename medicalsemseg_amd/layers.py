@@ -435,13 +435,20 @@ class Conv1:
         next_norm = (InstNormAct, yraw, stats, act) of the layer whose activation is this conv's input: its
         InstanceNorm-backward sums are then fused into the input-gradient kernel; returns (dx, red)."""
         dtype = x.dtype
+        fused_bias = False
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
             if self._gather(dtype):
                 WGRAD_SIDE.run(lambda: hip.conv3d_gather_wgrad(x, dy[..., :self.cout], g, self.cin, self.cout, 1, 1, 0, acc), x, dy)
+            elif hip.linear_wgrad_ok(x, self.cin, self.cout):
+                # weight and bias gradient from one pass over the voxels (csrc/linear_wgrad.hip)
+                gb, bacc = _grad_buf(self.b) if (self.b is not None and self.b.requires_grad) else (None, False)
+                WGRAD_SIDE.run(lambda: hip.linear_wgrad(x, dy[..., :self.cout], g.view(self.cout, self.cin), gb, self.cin,
+                                                        self.cout, acc, bacc), x, dy)
+                fused_bias = True
             else:
                 WGRAD_SIDE.run(lambda: hip.conv3d_k1_wgrad(x, dy[..., :self.cout], g, self.cin, self.cout, acc), x, dy)
-        if self.b is not None and self.b.requires_grad:
+        if self.b is not None and self.b.requires_grad and not fused_bias:
             g, acc = _grad_buf(self.b)
             hip.channel_sum(dy[..., :self.cout], g, acc)
         if not need_dx:

@@ -31,6 +31,22 @@ def _c(x):
     return x if x.is_contiguous() else x.contiguous()
 
 
+def _linear_param_grads(x, dy, weight, bias, cin, cout, want_w, want_b):
+    """weight.grad (+)= dy^T x, bias.grad (+)= dy.sum(tokens): one pass over the tokens where the fused kernel takes the shape"""
+    want_b = want_b and bias is not None
+    if want_w and hip.linear_wgrad_ok(x, cin, cout):
+        gw, aw = _gbuf(weight)
+        gb, ab = _gbuf(bias) if want_b else (None, False)
+        hip.linear_wgrad(x, dy, gw.view(cout, cin), gb, cin, cout, aw, ab)
+        return
+    if want_w:
+        g, acc = _gbuf(weight)
+        hip.conv3d_k1_wgrad(x, dy, g.view(cout, cin), cin, cout, acc)
+    if want_b:
+        g, acc = _gbuf(bias)
+        hip.channel_sum(dy, g, acc)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b on the last dim (nn.Linear): the 1x1x1 igemm on tokens."""
 
@@ -58,12 +74,7 @@ class LinearFn(torch.autograd.Function):
             wpd = _packed(weight, T, "d", lambda: hip.pack_conv_k1(weight.detach().reshape(cout, cin), T, dgrad=True))
             dx = torch.empty_like(x)
             hip.conv3d_k1(dy, wpd, None, dx, cout, cin)
-        if ctx.needs_input_grad[1]:
-            g, acc = _gbuf(weight)
-            hip.conv3d_k1_wgrad(x, dy, g.view(cout, cin), cin, cout, acc)
-        if bias is not None and ctx.needs_input_grad[2]:
-            g, acc = _gbuf(bias)
-            hip.channel_sum(dy, g, acc)
+        _linear_param_grads(x, dy, weight, bias, cin, cout, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, None, None
 
 
@@ -112,23 +123,13 @@ class MlpFn(torch.autograd.Function):
             dact = torch.empty_like(pre)
             hip.conv3d_k1(dy, wpd2, None, dact, cout, chid)
             hip.gelu_bwd(pre, dact, dpre)
-        if ctx.needs_input_grad[3]:
-            g, acc = _gbuf(w2)
-            hip.conv3d_k1_wgrad(act, dy, g.view(cout, chid), chid, cout, acc)
-        if b2 is not None and ctx.needs_input_grad[4]:
-            g, acc = _gbuf(b2)
-            hip.channel_sum(dy, g, acc)
+        _linear_param_grads(act, dy, w2, b2, chid, cout, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         dx = None
         if ctx.needs_input_grad[0]:
             wpd1 = _packed(w1, T, "d", lambda: hip.pack_conv_k1(w1.detach().reshape(chid, cin), T, dgrad=True))
             dx = torch.empty_like(x)
             hip.conv3d_k1(dpre, wpd1, None, dx, chid, cin)
-        if ctx.needs_input_grad[1]:
-            g, acc = _gbuf(w1)
-            hip.conv3d_k1_wgrad(x, dpre, g.view(chid, cin), cin, chid, acc)
-        if b1 is not None and ctx.needs_input_grad[2]:
-            g, acc = _gbuf(b1)
-            hip.channel_sum(dpre, g, acc)
+        _linear_param_grads(x, dpre, w1, b1, cin, chid, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, None, None, None, None
 
 
@@ -330,15 +331,10 @@ class PatchConvFn(torch.autograd.Function):
         dy = _c(dy)
         cout, cin = weight.shape[0], weight.shape[1]
         k = ctx.k
-        if bias is not None and ctx.needs_input_grad[2]:
-            g, acc = _gbuf(bias)
-            hip.channel_sum(dy, g, acc)
         if ctx.gemm:
             K = cin * k ** 3
             T = x.dtype
-            if ctx.needs_input_grad[1]:
-                g, acc = _gbuf(weight)
-                hip.conv3d_k1_wgrad(x, dy, g.view(cout, K), K, cout, acc)
+            _linear_param_grads(x, dy, weight, bias, K, cout, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
             dx = None
             if ctx.needs_input_grad[0]:
                 wpd = _packed(weight, T, "pd", lambda: hip.pack_conv_k1(weight.detach().reshape(cout, K), T, dgrad=True))
@@ -346,6 +342,9 @@ class PatchConvFn(torch.autograd.Function):
                 hip.conv3d_k1(dy, wpd, None, dxs, cout, K)
                 dx = _unpatchify(dxs, k, cin)
             return dx, None, None, None, None, None
+        if bias is not None and ctx.needs_input_grad[2]:
+            g, acc = _gbuf(bias)
+            hip.channel_sum(dy, g, acc)
         if ctx.needs_input_grad[1]:
             g, acc = _gbuf(weight)
             hip.conv3d_gather_wgrad(x, dy, g, cin, cout, k, ctx.s, ctx.p, acc)

@@ -523,6 +523,38 @@ def test_mlp_fused_gelu_equals_linear_gelu_linear(C, tokens):
     check(res[0][1], xr.grad, dtype, "mlp dx", scale=float(xr.grad.abs().max()))
 
 
+@pytest.mark.parametrize("tokens,cin,cout", [(4099, 48, 144), (700, 48, 192), (1000, 192, 48), (333, 48, 48), (129, 96, 288), (257, 384, 96),
+                                             (50, 144, 48), (432, 384, 1536), (64, 96, 48), (3001, 96, 96)])
+def test_linear_wgrad_one_pass_weight_and_bias(tokens, cin, cout):
+    """msseg_linear_wgrad (csrc/linear_wgrad.hip: weight and bias gradient of nn.Linear from one pass over the tokens) vs
+    torch on the bf16-rounded operands, write and accumulate forms, deterministic"""
+    from medicalsemseg_amd import hip
+    dev, dtype = _dev(), torch.bfloat16
+    x = gen(tokens, cin, seed=1).to(dev).to(dtype)
+    dy = gen(tokens, cout, seed=2).to(dev).to(dtype)
+    assert hip.linear_wgrad_ok(x, cin, cout)
+    dw = torch.full((cout, cin), float("nan"), device=dev)
+    db = torch.full((cout,), float("nan"), device=dev)
+    hip.linear_wgrad(x, dy, dw, db, cin, cout)
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    sw, sb = float(ref_w.abs().max()), float(ref_b.abs().max())
+    assert float((dw.double() - ref_w).abs().max()) / sw < 2e-5
+    assert float((db.double() - ref_b).abs().max()) / sb < 2e-5
+    dw2, db2 = dw.clone(), db.clone()
+    hip.linear_wgrad(x, dy, dw2, db2, cin, cout, True, True)
+    assert float((dw2.double() - 2 * ref_w).abs().max()) / sw < 4e-5 and float((db2.double() - 2 * ref_b).abs().max()) / sb < 4e-5
+    dw3 = torch.empty_like(dw)
+    hip.linear_wgrad(x, dy, dw3, None, cin, cout)            # weight only
+    assert torch.equal(dw3, dw)
+    # channel slices of wider buffers (qkv gradient slices, concat halves)
+    big_x = torch.zeros(tokens, cin + 16, device=dev, dtype=dtype); big_x[:, 8:8 + cin] = x
+    big_dy = torch.zeros(tokens, cout + 8, device=dev, dtype=dtype); big_dy[:, :cout] = dy
+    dw4, db4 = torch.empty_like(dw), torch.empty_like(db)
+    hip.linear_wgrad(big_x[:, 8:8 + cin], big_dy[:, :cout], dw4, db4, cin, cout)
+    assert torch.equal(dw4, dw) and torch.equal(db4, db)
+
+
 def test_flat_adamw_matches_torch_adamw():
     """fused flat-buffer AdamW (+ weight-decay grouping, + folded gradient clipping) vs torch.optim.AdamW"""
     from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay

@@ -50,8 +50,12 @@ for tok, cin, cout in SHAPES:
     db = torch.zeros(cout, device=dev)
     t = [timed(lambda: hip.conv3d_k1(x, wp, b, y, cin, cout)), timed(lambda: hip.conv3d_k1(dy, wpd, None, dx, cout, cin)),
          timed(lambda: hip.conv3d_k1_wgrad(x, dy, dw, cin, cout)), timed(lambda: hip.channel_sum(dy, db))]
+    tf = timed(lambda: hip.linear_wgrad(x, dy, dw, db, cin, cout)) if hip.linear_wgrad_ok(x, cin, cout) else float("nan")
+    totf = globals().get("totf", 0.0) + tf
+    globals()["totf"] = totf
     for i in range(4):
         tot[i] += t[i]
     hb = tok * (cin + cout) * 2 / 8e6
-    print(f"{tok:6d} {cin:4d}->{cout:4d} | {t[0]:5.1f}  {t[1]:5.1f}  {t[2]:5.1f}  {t[3]:5.1f} | {hb:5.1f}", flush=True)
+    print(f"{tok:6d} {cin:4d}->{cout:4d} | {t[0]:5.1f}  {t[1]:5.1f}  {t[2]:5.1f}  {t[3]:5.1f} | {hb:5.1f} | one-pass wgrad+dbias {tf:5.1f}", flush=True)
+print(f"one-pass wgrad+dbias sum {totf:6.1f}")
 print(f"sum (x2 blocks per stage for the first 16 rows not applied) | {tot[0]:6.1f} {tot[1]:6.1f} {tot[2]:6.1f} {tot[3]:6.1f}")
