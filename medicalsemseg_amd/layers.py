@@ -270,24 +270,33 @@ class Conv3:
             return y, (stats if stats is not None else hip.channel_stats(y))
         return y
 
-    def halves_ok(self, vol, dtype) -> bool:
-        """96 input channels on a grid the 48-channel ping-pong kernel takes (Swin-UNETR's decoder convs over cat(up, skip))"""
-        return (self.cin == 96 and dtype == torch.bfloat16 and not os.environ.get("MSSEG_NO_SPLIT_CAT")
-                and hip.lib().msseg_conv3d_k3_kernel(*vol, 48, self.cout, hip.BF16) == 4)
+    def halves_ok(self, vol, dtype) -> int:
+        """channels per half if conv(x) on this grid can run as two launches of a ping-pong kernel on the channel halves of x
+        (a concat buffer): 96 input channels -> 2 x 48 (Swin-UNETR's decoder convs over cat(up, skip), csrc/conv3d_k3_c48.hip);
+        0 otherwise"""
+        if dtype != torch.bfloat16 or os.environ.get("MSSEG_NO_SPLIT_CAT"):
+            return 0
+        if self.cin == 96 and hip.lib().msseg_conv3d_k3_kernel(*vol, 48, self.cout, hip.BF16) == 4:
+            return 48
+        # 64 -> 2 x 32 on the 32-channel ping-pong kernel (BasicUNet's UpCat convs in TRAINING, where the concat buffer exists
+        # anyway for the weight gradient) measured neutral: 4.031 vs 4.026 ms per step -- the second launch's read-back of
+        # the stored sums costs what the faster kernel gains; the inference forward (fwd_split: no concat buffer) keeps it
+        return 0
 
     def fwd_halves(self, x):
-        """y = conv(x[96 ch]) + bias as two launches of the 48-channel kernel on the two channel halves of x (the concat
-        buffer): the second adds its sums onto the stored result of the first and emits the InstanceNorm statistics.  The
-        generic kernel pads 96 -> 48 to 3 x 32 input and 2 x 32 output channels and runs one stage after the other; the
-        intermediate sum is rounded to bf16 once more than there.  Returns (y, stats)."""
+        """y = conv(x) + bias as two launches on the two channel halves of x (the concat buffer): the second adds its sums onto
+        the stored result of the first and emits the InstanceNorm statistics.  The generic kernel runs such layers one
+        32-channel stage after the other (and pads 96 -> 48 to 3 x 32 input and 2 x 32 output channels); the intermediate
+        sum is rounded to bf16 once more than there.  Returns (y, stats)."""
         dtype, vol = x.dtype, tuple(x.shape[:4])
-        wa, wb = self.w.detach()[:, :48], self.w.detach()[:, 48:]
-        pa = self.cache.get(wa, dtype, ("fa48", vol), lambda: hip.pack_conv_k3(wa, dtype, vol=vol))
-        pb = self.cache.get(wb, dtype, ("fb48", vol), lambda: hip.pack_conv_k3(wb, dtype, vol=vol))
+        h = self.halves_ok(vol, dtype)
+        wa, wb = self.w.detach()[:, :h], self.w.detach()[:, h:]
+        pa = self.cache.get(wa, dtype, ("fa", h, vol), lambda: hip.pack_conv_k3(wa, dtype, vol=vol))
+        pb = self.cache.get(wb, dtype, ("fb", h, vol), lambda: hip.pack_conv_k3(wb, dtype, vol=vol))
         y = _empty_like_vol(x, self.cout)
-        hip.conv3d_k3(x[..., :48], pa, self.b, y, 48, self.cout)
+        hip.conv3d_k3(x[..., :h], pa, self.b, y, h, self.cout)
         stats = torch.empty(x.shape[0], self.cout, 2, dtype=torch.float32, device=x.device)
-        hip.conv3d_k3_accumulate(x[..., 48:], pb, y, 48, self.cout, stats)
+        hip.conv3d_k3_accumulate(x[..., h:], pb, y, h, self.cout, stats)
         return y, stats
 
     def split_ok(self, vol, dtype, ca, cb_) -> bool:

@@ -104,7 +104,7 @@ def test_conv3d_k3_96_channels_as_two_48_channel_launches(sp, N):
     yref = F.conv3d(xr, wr, b, padding=1)
     op = Conv3(torch.nn.Parameter(w.to(dev)), torch.nn.Parameter(b.to(dev)))
     xg = cl(x, dtype, dev)
-    assert op.halves_ok((N, *sp), dtype)
+    assert op.halves_ok((N, *sp), dtype) == 48
     y, stats = op.fwd(xg, want_stats=True)
     check(ncdhw(y), yref, dtype, "conv 96 -> 48 as two halves")
     yf = y.float().reshape(N, -1, 48)
