@@ -24,6 +24,14 @@
 //
 // MFMA operand roles: A = weights (rows = cout), B = activations (cols = voxels), so a lane holds 4 consecutive
 // couts of one voxel: 8-byte channels-last stores.
+//
+// Halo image (round 3): voxel-major [halo voxel][64 B] -- the 64 lanes of one LDS-DMA instruction fetch 16 voxels x 4 chunks,
+// i.e. 1 KB of consecutive memory on a dense 32-channel tensor (8 cache lines; the chunk-planar image of rounds 1-2 had a
+// lane per voxel: 32 lines per instruction, and the instruction's issue cost follows the lines).  A 64-byte voxel pitch
+// alone puts voxels v and v + 4 on the same banks; chunk q of voxel v therefore sits in slot q ^ 2*bit2(v), applied on the
+// DMA's SOURCE chunk (the LDS side of a DMA is lane-linear): the 16 lanes of a ds_read_b128 group (voxels b .. b+15 at two
+// adjacent q) then cover the 16 slots of a 256-byte bank window exactly once for every b.  bit2(v) of a read at
+// lane voxel + constant offset depends on (offset mod 8): eight per-lane base addresses, the offset stays an immediate.
 #include "k3pp.h"
 
 #include <type_traits>
@@ -36,7 +44,6 @@ constexpr int HV = PD * PH * PW;                        // 648 halo voxels
 constexpr int PLANE = ((HV * 16 + 255) / 256) * 256;    // one 16-byte channel chunk of every halo voxel
 constexpr int HALO_BYTES = 4 * PLANE;
 constexpr int W_BYTES = 27 * 4 * 32 * 16;
-constexpr int NIT_H = (HV + 63) / 64;                   // LDS-DMA instructions per plane
 constexpr int STAT_FLOATS = 8 * MSSEG_STATS_NMAX * 32 * 2;
 constexpr int NTHREADS = 512;
 
@@ -100,39 +107,44 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
         return tc;
     };
 
-    // ---- halo fill: wave wq of a group fills channel-chunk plane wq of the group's image.
+    // ---- halo fill: wave wq of a group issues DMA pieces wq, wq + 4, ... (1 KB each = 16 halo voxels x 4 slots).
     // The memory role shares its SIMD with a wave that issues MFMAs back to back, so its VALU instructions get an
     // issue slot only every few cycles: everything per-lane is precomputed (byte offsets relative to the tile's halo
     // origin), the per-tile part is scalar, and an interior tile costs no vector ALU work at all per load.
-    unsigned h_off[NIT_H];
+    constexpr int NPIECE = (HV + 15) / 16;              // 41
+    constexpr int NIT_P = (NPIECE + 3) / 4;             // 11 per wave
+    unsigned h_off[NIT_P];
 #pragma unroll
-    for (int it = 0; it < NIT_H; ++it) {
-        const int hv = it * 64 + lane;
+    for (int it = 0; it < NIT_P; ++it) {
+        const int hv = (wq + 4 * it) * 16 + (lane >> 2);
         const int hd = hv / (PH * PW), rem = hv - hd * (PH * PW), hh = rem / PW, hw = rem - hh * PW;
-        h_off[it] = (unsigned)((((long long)hd * p.H + hh) * p.W + hw) * p.ldx * 2 + wq * 16);
+        const int chunk = (lane & 3) ^ (((hv >> 2) & 1) << 1);
+        h_off[it] = (unsigned)((((long long)hd * p.H + hh) * p.W + hw) * p.ldx * 2 + chunk * 16);
     }
-    const bool last_ok = lane < HV - 64 * (NIT_H - 1);
+    auto piece_ok = [&](int it) {                       // piece exists / lane's voxel inside the halo
+        return (wq + 4 * it) * 16 + (lane >> 2) < HV;
+    };
     auto load_halo = [&](const TileCo& tc) {
-        unsigned char* dst = ldsH + grp * HALO_BYTES + wq * PLANE;
+        unsigned char* dst = ldsH + grp * HALO_BYTES + wq * 1024;
         const int dB = tc.d0 - 1, hB = tc.h0 - 1, wB = tc.w0 - 1;
         const long long vox = (((long long)tc.n * p.D + dB) * p.H + hB) * p.W + wB;
         const unsigned char* hbase = (const unsigned char*)xg + vox * p.ldx * 2;
         const bool interior = dB >= 0 && dB + PD <= p.D && hB >= 0 && hB + PH <= p.H && wB >= 0 && wB + PW <= p.W;
         if (interior) {
 #pragma unroll
-            for (int it = 0; it < NIT_H; ++it) {
-                if (it < NIT_H - 1 || last_ok) glds16(hbase + h_off[it], dst + it * 1024);
+            for (int it = 0; it < NIT_P; ++it) {
+                if (piece_ok(it)) glds16(hbase + h_off[it], dst + it * 4096);
             }
         } else {
             const unsigned char* zsrc = (const unsigned char*)&g_zero_chunk;
 #pragma unroll
-            for (int it = 0; it < NIT_H; ++it) {
-                const int hv = it * 64 + lane;
+            for (int it = 0; it < NIT_P; ++it) {
+                const int hv = (wq + 4 * it) * 16 + (lane >> 2);
                 const int hd = hv / (PH * PW), rem = hv - hd * (PH * PW), hh = rem / PW, hw = rem - hh * PW;
                 const bool inb = (unsigned)(dB + hd) < (unsigned)p.D && (unsigned)(hB + hh) < (unsigned)p.H &&
                                  (unsigned)(wB + hw) < (unsigned)p.W;
                 const unsigned char* src = inb ? hbase + h_off[it] : zsrc;
-                if (it < NIT_H - 1 || last_ok) glds16(src, dst + it * 1024);
+                if (piece_ok(it)) glds16(src, dst + it * 4096);
             }
         }
     };
@@ -165,7 +177,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
         for (int m = 0; m < TH; ++m)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[m][j] = bv[j];
-        const unsigned char* xb = ldsH + grp * HALO_BYTES + q * PLANE + ((wq * PH) * PW + r) * 16;
+        // lane voxel (wq * PH) * PW + r of the image; xb[k] = its address for a read at a voxel offset == k (mod 8)
+        const int v0 = (wq * PH) * PW + r;
+        const unsigned char* xb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            xb[k] = ldsH + grp * HALO_BYTES + v0 * 64 + ((q ^ ((((v0 + k) >> 2) & 1) << 1)) * 16);
         const unsigned char* wb = ldsW + (q * 32 + r) * 16;
         constexpr int NSTEP = 9 * PH;       // (kd, kw) x halo row
         constexpr int XAHEAD = 3;           // activation fragments in flight ahead of their MFMAs
@@ -177,7 +194,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k3pp_kernel(const K3ppParams p) {
         };
         auto ldx = [&](int s) {             // s = g * PH + hr
             const int g = s / PH, hr = s % PH;
-            xf[s % (XAHEAD + 1)] = *(const u32x4_t*)(xb + (((g / 3) * PH + hr) * PW + (g % 3)) * 16);
+            const int off = ((g / 3) * PH + hr) * PW + (g % 3);
+            xf[s % (XAHEAD + 1)] = *(const u32x4_t*)(xb[off & 7] + off * 64);
         };
 #pragma unroll
         for (int i = 0; i < 6; ++i) ldw(0, i);
