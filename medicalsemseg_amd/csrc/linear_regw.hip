@@ -148,6 +148,75 @@ template <int KS, int NH, int EPI = EPI_NONE> int launch(const LinParams& p, int
     return MSSEG_OK;
 }
 
+// ---- few tokens, deep K (the last Swin stage: 432 tokens x 1152 ... 1536 input channels; MONAI variant: 54 x 3072) ----
+// The streaming kernel above cannot hold K / 32 > 24 weight fragments per output tile, and the generic flat kernel walks K in 32-
+// channel stages behind a load -> LDS -> barrier round trip each on two dozen workgroups: 48-64 us for 0.5 GFLOP.  Here the four
+// waves of a workgroup split K (KSW k-steps each) for the same 16 tokens x NH output tiles, every wave holds its NH x KSW weight
+// fragments and its KSW token chunks in registers at once (all loads in flight together), and the four partial tiles meet in
+// LDS (fixed order, deterministic).  Grid = token groups x output slices: hundreds of workgroups for a one-round launch.
+template <int KSW, int NH>
+__global__ __launch_bounds__(LR_THREADS, 2) void linear_ksplit_kernel(const LinParams p) {
+    __shared__ __attribute__((aligned(16))) float xch[3][NH][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int mbase = blockIdx.y * NH * 16;
+    const int kstot = (p.K + 31) / 32;              // k-steps of the packed image
+    const int k0 = wave * KSW;
+    const long long v = (long long)blockIdx.x * 16 + r;
+    const bool valid = v < p.NV;
+    const bf16_t* __restrict__ xg = (const bf16_t*)p.x;
+    u32x4_t bx[KSW];
+#pragma unroll
+    for (int k = 0; k < KSW; ++k)
+        bx[k] = valid ? ldg16(xg + v * p.ldx + (k0 + k) * 32 + q * 8) : u32x4_t{0u, 0u, 0u, 0u};
+    f32x4_t acc[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int m0 = mbase + j * 16;
+        const int blk = m0 / p.cb, row = m0 - blk * p.cb + r;
+        u32x4_t af[KSW];
+#pragma unroll
+        for (int k = 0; k < KSW; ++k)
+            af[k] = ldg16((const unsigned char*)p.wp + ((((long long)blk * kstot + k0 + k) * 4 + q) * p.cb + row) * 16);
+        acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (wave == 0 && p.bias) acc[j] = *(const f32x4_t*)(p.bias + m0 + q * 4);
+#pragma unroll
+        for (int k = 0; k < KSW; ++k) mma_chunk<bf16_t>(acc[j], af[k], bx[k]);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < NH; ++j) *(f32x4_t*)xch[wave - 1][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0 && valid) {
+        bf16_t* __restrict__ yg = (bf16_t*)p.y + v * p.ldy + mbase + q * 4;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const f32x4_t a1 = *(const f32x4_t*)xch[0][j][lane], a2 = *(const f32x4_t*)xch[1][j][lane], a3 = *(const f32x4_t*)xch[2][j][lane];
+            const f32x4_t o = (acc[j] + a1) + (a2 + a3);
+            *(u32x2_t*)(yg + j * 16) = u32x2_t{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        }
+    }
+}
+
+// k-steps per wave with an instantiation: K = 128 * KSW input channels
+static bool ksplit_ok(int Cin, int Cout, long long NV) {
+    if (Cin % 128 || Cout % 16 || NV > 4096) return false;
+    const int ksw = Cin / 128;
+    return ksw == 9 || ksw == 12 || ksw == 24;
+}
+
+template <int KSW> int launch_ksplit(const LinParams& p, int Cout, hipStream_t stream) {
+    const unsigned gx = (unsigned)((p.NV + 15) / 16);
+    if (KSW <= 12 && Cout % 32 == 0) {
+        hipLaunchKernelGGL((linear_ksplit_kernel<KSW, 2>), dim3(gx, (unsigned)(Cout / 32)), dim3(LR_THREADS), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((linear_ksplit_kernel<KSW, 1>), dim3(gx, (unsigned)(Cout / 16)), dim3(LR_THREADS), 0, stream, p);
+    }
+    MSSEG_CHECK_LAUNCH("linear_ksplit");
+    return MSSEG_OK;
+}
+
 constexpr int MAX_FRAGS = 24;   // weight fragments per lane (96 VGPRs)
 
 // output tiles per workgroup: the widest of {12, 9, 6, 4, 3, 2, 1} that divides the layer and fits the register budget
@@ -182,7 +251,7 @@ bool msseg_linear_regw_eligible(int dtype, long long NV, int Cin, int Cout, cons
     static const bool off = getenv("MSSEG_NO_LINEAR_REGW") != nullptr;   // A/B switch
     if (off || dtype != MSSEG_BF16 || NV < 1 || Cout % 16 || Cin % 8) return false;
     const int ks = (Cin + 31) / 32;
-    if (!lr_ks_ok(ks) || pick_nh(ks, Cout) == 0) return false;
+    if ((!lr_ks_ok(ks) || pick_nh(ks, Cout) == 0) && !ksplit_ok(Cin, Cout, NV)) return false;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (ldx % 8) || (ldy % 8) || ldx < Cin || ldy < Cout) return false;
     if (bias && ((uintptr_t)bias & 15)) return false;
     return true;
@@ -194,7 +263,14 @@ int msseg_linear_regw_launch(const void* x, long long ldx, const void* wp, const
     p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy; p.NV = NV; p.K = Cin;
     p.cb = msseg_cout_block(Cout);
     const int ks = (Cin + 31) / 32, nh = pick_nh(ks, Cout);
-    if (!lr_ks_ok(ks) || nh == 0) MSSEG_FAIL(MSSEG_EINVAL, "linear_regw: shape %d -> %d has no instantiation", Cin, Cout);
+    if (!lr_ks_ok(ks) || nh == 0) {
+        if (!ksplit_ok(Cin, Cout, NV)) MSSEG_FAIL(MSSEG_EINVAL, "linear_regw: shape %d -> %d has no instantiation", Cin, Cout);
+        switch (Cin / 128) {
+            case 9: return launch_ksplit<9>(p, Cout, stream);
+            case 12: return launch_ksplit<12>(p, Cout, stream);
+            default: return launch_ksplit<24>(p, Cout, stream);
+        }
+    }
     const int slices = Cout / (nh * 16);
     switch (ks) {
         case 2: return launch_ks<2>(p, nh, slices, stream);

@@ -489,6 +489,28 @@ def test_conv3d_k3_kernel_choice():
     assert L.msseg_conv3d_k3_kernel(2, 12, 12, 12, 48, 48, hip.BF16) in (1, 2)
 
 
+@pytest.mark.parametrize("tokens,cin,cout", [(432, 1536, 384), (432, 1152, 384), (54, 3072, 768), (433, 1536, 48), (17, 1152, 16), (4096, 1536, 96)])
+def test_linear_few_tokens_deep_k(tokens, cin, cout):
+    """conv3d_k1 / Linear on few tokens with K = 1152 ... 3072 (last Swin stage): the workgroup's four waves split K
+    (linear_ksplit_kernel, csrc/linear_regw.hip); with and without bias, output as a channel slice of a wider buffer"""
+    from medicalsemseg_amd import hip
+    dev, dtype = _dev(), torch.bfloat16
+    x = gen(tokens, cin, seed=1)
+    w = gen(cout, cin, seed=2, scale=cin ** -0.5)
+    b = gen(cout, seed=3)
+    xr, wr = rnd(dtype, x, w)
+    ref = F.linear(xr, wr, b)
+    wp = hip.pack_conv_k1(w.to(dev), dtype)
+    xg = x.to(dev, dtype)
+    y = torch.empty(tokens, cout, device=dev, dtype=dtype)
+    hip.conv3d_k1(xg, wp, b.to(dev), y, cin, cout)
+    check(y, ref, dtype, "few-token linear")
+    big = torch.full((tokens, cout + 16), 7.0, device=dev, dtype=dtype)
+    hip.conv3d_k1(xg, wp, None, big[:, 8:8 + cout], cin, cout)
+    check(big[:, 8:8 + cout], F.linear(xr, wr), dtype, "few-token linear, no bias, slice")
+    assert float((big[:, :8].float() - 7).abs().max()) == 0 and float((big[:, 8 + cout:].float() - 7).abs().max()) == 0
+
+
 @pytest.mark.parametrize("C,tokens", [(48, (2, 9, 11, 13)), (96, (1, 6, 7, 8)), (192, (1, 3, 5, 7)), (384, (1, 3, 3, 3)), (40, (1, 4, 5, 6))])
 def test_mlp_fused_gelu_equals_linear_gelu_linear(C, tokens):
     """ops.mlp (GELU in the epilogues of fc1 and of fc2's input gradient, csrc/linear_regw.hip) == ops.linear -> ops.gelu ->
@@ -524,7 +546,7 @@ def test_mlp_fused_gelu_equals_linear_gelu_linear(C, tokens):
 
 
 @pytest.mark.parametrize("tokens,cin,cout", [(4099, 48, 144), (700, 48, 192), (1000, 192, 48), (333, 48, 48), (129, 96, 288), (257, 384, 96),
-                                             (50, 144, 48), (432, 384, 1536), (64, 96, 48), (3001, 96, 96)])
+                                             (50, 144, 48), (1100, 384, 1536), (64, 96, 48), (3001, 96, 96)])
 def test_linear_wgrad_one_pass_weight_and_bias(tokens, cin, cout):
     """msseg_linear_wgrad (csrc/linear_wgrad.hip: weight and bias gradient of nn.Linear from one pass over the tokens) vs
     torch on the bf16-rounded operands, write and accumulate forms, deterministic"""
@@ -746,7 +768,10 @@ def test_conv3d_k1_head(dtype, cin, cout):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,C,affine", [((2, 3, 3, 3), 3072, True), ((2, 3, 3, 3), 1536, True), ((1, 5, 6, 7), 384, True),
-                                            ((2, 6, 7, 8), 48, False), ((1, 4, 5, 6), 40, True), ((1, 2, 2, 3), 4104, True)])
+                                            ((2, 6, 7, 8), 48, False), ((1, 4, 5, 6), 40, True), ((1, 2, 2, 3), 4104, True),
+                                            # many rows per lane: the parameter-gradient partial rows of the backward kernel
+                                            ((2, 24, 24, 24), 48, True), ((1, 12, 12, 12), 96, True), ((1, 6, 6, 6), 192, True),
+                                            ((1, 5, 6, 7), 768, True), ((1, 3, 3, 3), 1024, True)])
 def test_layer_norm_wide_and_narrow_rows(dtype, rows, C, affine):
     """ops.layer_norm forward / backward vs torch on the rounded operands: the vector kernel up to 8 chunks per lane (the
     3072-wide LayerNorm of the MONAI variant's last patch merging: /root/reference/models/segmentors/swin_unetr_official.py:699-708),
