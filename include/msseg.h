@@ -249,6 +249,12 @@ int msseg_conv3d_k3_small_fwd_finish(const float* part, int nstages, const float
                                      const float* beta, float eps, float slope, void* yraw, long long ldy, void* act,
                                      long long lda, void* pooled, long long ldp, float* stats, int N, int D, int H, int W,
                                      int Cout, msseg_stream_t stream);
+/* ... with an optional residual added before the LeakyReLU: act = lrelu(instance_norm(y) * gamma + beta + residual) -- the
+ * second convolution of MONAI's UnetResBlock (models/segmentors/swin_unetr.py:73-128 of the reference) */
+int msseg_conv3d_k3_small_fwd_finish_res(const float* part, int nstages, const float* bias, const float* gamma,
+                                         const float* beta, float eps, float slope, void* yraw, long long ldy, void* act,
+                                         long long lda, const void* residual, long long ldr, void* pooled, long long ldp,
+                                         float* stats, int N, int D, int H, int W, int Cout, msseg_stream_t stream);
 int msseg_conv3d_k3_small_bwd_finish(const float* part, int nstages, void* dx, long long lddx, const void* unit_yraw,
                                      long long lduy, const float* unit_stats, const float* unit_gamma,
                                      const float* unit_beta, float eps, float slope, float* dgamma, float* dbeta,

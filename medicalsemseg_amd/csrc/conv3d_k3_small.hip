@@ -148,9 +148,11 @@ __global__ __launch_bounds__(256, 2) void k3s_kernel(const K3sParams p) {
             const int v = (f0 + f) * 16 + r;
             if (v < TV) {
                 const int vw = v % TS, vh = (v / TS) % TS, vd = v / (TS * TS);
-                const long long gv = (((long long)n * p.D + td0 + vd) * p.H + th0 + vh) * p.W + tw0 + vw;
-                *(f32x4_t*)(po + gv * 4) = acc[f][0];
-                *(f32x4_t*)(po + (4 * NV + gv) * 4) = acc[f][1];
+                if (td0 + vd < p.D && th0 + vh < p.H && tw0 + vw < p.W) {      // edge tiles of grids that are not tile multiples
+                    const long long gv = (((long long)n * p.D + td0 + vd) * p.H + th0 + vh) * p.W + tw0 + vw;
+                    *(f32x4_t*)(po + gv * 4) = acc[f][0];
+                    *(f32x4_t*)(po + (4 * NV + gv) * 4) = acc[f][1];
+                }
             }
         }
     }
@@ -165,6 +167,7 @@ struct K3sFinParams {
     const float* gamma; const float* beta; float eps, slope;
     bf16_t* yraw; long long ldy;
     bf16_t* act; long long lda;
+    const bf16_t* res; long long ldr;            // optional residual added before the LeakyReLU (UnetResBlock's second conv)
     bf16_t* pooled; long long ldp;
     float* stats;                                // [N][M][2] (sum, sum of squares) of the stored raw output
     // backward
@@ -291,9 +294,11 @@ __global__ __launch_bounds__(BS) void k3s_fwd_finish_kernel(const K3sFinParams p
     for (int i = 0; i < VPT; ++i) {
         if (ok[i]) {
             bf16x4_t o;
+            bf16x4_t rv = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (p.res) rv = *(const bf16x4_t*)(p.res + row[i] * p.ldr + c0);
 #pragma unroll
             for (int e = 0; e < FCH; ++e) {
-                const float z = y[i][e] * sc[e] + sh[e];
+                const float z = y[i][e] * sc[e] + sh[e] + (float)rv[e];      // as msseg_instnorm_act_fwd: one rounding at the end
                 o[e] = (bf16_t)(z > 0.f ? z : z * p.slope);
             }
             if (!(p.dbg & 1)) *(bf16x4_t*)(p.act + row[i] * p.lda + c0) = o;
@@ -450,8 +455,7 @@ __global__ __launch_bounds__(BS) void k3s_bwd_unit_kernel(const K3sFinParams p) 
 int k3s_check(const void* x, long long ldx, const void* wp, const void* part, int N, int D, int H, int W, int K, int M,
               const char* who) {
     if (!x || !wp || !part) MSSEG_FAIL(MSSEG_EINVAL, "%s: null pointer", who);
-    if (N < 1 || D < 1 || H < 1 || W < 1 || D % TSD || H % TS || W % TS)
-        MSSEG_FAIL(MSSEG_EINVAL, "%s: spatial dims %dx%dx%d must be multiples of %dx%dx%d", who, D, H, W, TSD, TS, TS);
+    if (N < 1 || D < 1 || H < 1 || W < 1) MSSEG_FAIL(MSSEG_EINVAL, "%s: bad spatial dims %dx%dx%d", who, D, H, W);
     if (K < 32 || M < 32 || K % 32 || M % 32) MSSEG_FAIL(MSSEG_EINVAL, "%s: channels %d -> %d must be multiples of 32", who, K, M);
     if (ldx < K || ldx % 8 || ((uintptr_t)x & 15) || ((uintptr_t)wp & 15) || ((uintptr_t)part & 15))
         MSSEG_FAIL(MSSEG_EINVAL, "%s: 16-byte aligned tensors with a voxel stride that is a multiple of 8", who);
@@ -464,16 +468,18 @@ extern "C" {
 
 int msseg_conv3d_k3_small_ok(int N, int D, int H, int W, int Cin, int Cout, int dtype) {
     if (dtype != MSSEG_BF16 || N < 1 || N > MSSEG_STATS_NMAX) return 0;
-    if (D < TSD || H < TS || W < TS || D % TSD || H % TS || W % TS) return 0;
+    // whole tiles (the 12^3 / 6^3 levels), or the 3^3 grid of Swin-UNETR's bottleneck (one quarter-filled tile per sample:
+    // the layer is 32 MB of weights for 54 voxels, what counts is that every workgroup streams a different slice of them)
+    const bool whole = D >= TSD && H >= TS && W >= TS && D % TSD == 0 && H % TS == 0 && W % TS == 0;
+    if (!whole && !(D == 3 && H == 3 && W == 3)) return 0;
     if ((long long)D * H * W > 1024 * 2) return 0;               // the finish kernels hold a (sample, 4 channel) slab per workgroup
-    if (D % 2 || H % 2 || W % 2) return 0;
     return (Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0 && Cin / 32 <= 64) ? 1 : 0;
 }
 
 /* stages per workgroup: the fewest that keep the grid within one round of two workgroups per CU and the stage groups
  * within what a finish thread sums at once */
 static int k3s_kpw(int N, int D, int H, int W, int Cin, int Cout) {
-    const long long units = (long long)N * (D / TSD) * (H / TS) * (W / TS) * (Cout / 32);
+    const long long units = (long long)N * ceil_div(D, TSD) * ceil_div(H, TS) * ceil_div(W, TS) * (Cout / 32);
     const int nks = Cin / 32;
     int kpw = 1;
     while (kpw < nks && (units * ceil_div(nks, kpw) > 2LL * msseg_num_cus() || ceil_div(nks, kpw) > NKG_MAX)) kpw *= 2;
@@ -498,7 +504,7 @@ int msseg_conv3d_k3_small_partials(const void* x, long long ldx, const void* wp,
         MSSEG_FAIL(MSSEG_EWORKSPACE, "conv3d_k3_small_partials: workspace %zu B < %zu B", part_bytes,
                    msseg_conv3d_k3_small_workspace_bytes(N, D, H, W, Cin, Cout));
     const int kpw = k3s_kpw(N, D, H, W, Cin, Cout);
-    K3sParams p{(const bf16_t*)x, ldx, (const bf16_t*)wp, part, N, D, H, W, Cin, Cout, D / TSD, H / TS, W / TS, kpw};
+    K3sParams p{(const bf16_t*)x, ldx, (const bf16_t*)wp, part, N, D, H, W, Cin, Cout, ceil_div(D, TSD), ceil_div(H, TS), ceil_div(W, TS), kpw};
     static msseg_lds_attr_once attr;
     if (!attr.ensure((const void*)k3s_kernel, K3S_LDS)) MSSEG_FAIL(MSSEG_ELAUNCH, "conv3d_k3_small: cannot set dynamic LDS size %d", K3S_LDS);
     const long long tiles = (long long)N * p.td * p.th * p.tw;
@@ -516,6 +522,16 @@ int msseg_conv3d_k3_small_fwd_finish(const float* part, int nstages, const float
                                      const float* beta, float eps, float slope, void* yraw, long long ldy, void* act,
                                      long long lda, void* pooled, long long ldp, float* stats, int N, int D, int H, int W,
                                      int Cout, msseg_stream_t stream) {
+    return msseg_conv3d_k3_small_fwd_finish_res(part, nstages, bias, gamma, beta, eps, slope, yraw, ldy, act, lda, nullptr, 0,
+                                                pooled, ldp, stats, N, D, H, W, Cout, stream);
+}
+
+int msseg_conv3d_k3_small_fwd_finish_res(const float* part, int nstages, const float* bias, const float* gamma,
+                                         const float* beta, float eps, float slope, void* yraw, long long ldy, void* act,
+                                         long long lda, const void* residual, long long ldr, void* pooled, long long ldp,
+                                         float* stats, int N, int D, int H, int W, int Cout, msseg_stream_t stream) {
+    if (residual && (ldr % 4 || ((uintptr_t)residual & 7)))
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_small_fwd_finish: the residual must be 8-byte aligned with a stride that is a multiple of 4");
     if (!part || !yraw || !act || !stats || nstages < 1 || nstages > NKG_MAX)
         MSSEG_FAIL(MSSEG_EINVAL, "conv3d_k3_small_fwd_finish: bad args (1 ... %d stage groups)", NKG_MAX);
     const int S = D * H * W;
@@ -527,6 +543,7 @@ int msseg_conv3d_k3_small_fwd_finish(const float* part, int nstages, const float
     p.part = part; p.nks = nstages; p.NV = (long long)N * S; p.N = N; p.D = D; p.H = H; p.W = W; p.M = Cout; p.bias = bias;
     p.gamma = gamma; p.beta = beta; p.eps = eps; p.slope = slope;
     p.yraw = (bf16_t*)yraw; p.ldy = ldy; p.act = (bf16_t*)act; p.lda = lda; p.pooled = (bf16_t*)pooled; p.ldp = ldp; p.stats = stats;
+    p.res = (const bf16_t*)residual; p.ldr = ldr;
     static const int dbg = getenv("MSSEG_K3S_DBG") ? atoi(getenv("MSSEG_K3S_DBG")) : 0;
     p.dbg = dbg;
     const int lds = pooled ? S * 8 : 0;

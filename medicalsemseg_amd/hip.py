@@ -126,6 +126,8 @@ SIGNATURES = {
     "msseg_conv3d_k3_small_partials": ([_vp, _ll, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_conv3d_k3_small_fwd_finish": ([_vp, _i, _vp, _vp, _vp, _f, _f, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i,
                                           _i, _vp], _i),
+    "msseg_conv3d_k3_small_fwd_finish_res": ([_vp, _i, _vp, _vp, _vp, _f, _f, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i,
+                                              _i, _vp], _i),
     "msseg_conv3d_k3_small_bwd_finish": ([_vp, _i, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _i,
                                           _i, _vp], _i),
     "msseg_avgpool3d_k3": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -549,12 +551,14 @@ def conv3d_k3_small_partials(x, wp, cin, cout):
     return part, ng
 
 
-def conv3d_k3_small_fwd_finish(part, nstages, bias, gamma, beta, eps, slope, yraw, act, pooled, stats):
+def conv3d_k3_small_fwd_finish(part, nstages, bias, gamma, beta, eps, slope, yraw, act, pooled, stats, residual=None):
+    """residual (optional, same shape as act): act = lrelu(instance_norm(y) * gamma + beta + residual)"""
     _need_gpu(part, yraw, act, stats)
     N, D, H, W, cout = yraw.shape
-    _ck(lib().msseg_conv3d_k3_small_fwd_finish(_p(part), nstages, _p(bias), _p(gamma), _p(beta), eps, slope, _p(yraw), ld(yraw),
-                                               _p(act), ld(act), _p(pooled), ld(pooled) if pooled is not None else 0,
-                                               _p(stats), N, D, H, W, cout, _stream()), "conv3d_k3_small_fwd_finish")
+    _ck(lib().msseg_conv3d_k3_small_fwd_finish_res(_p(part), nstages, _p(bias), _p(gamma), _p(beta), eps, slope, _p(yraw), ld(yraw),
+                                                   _p(act), ld(act), _p(residual), ld(residual) if residual is not None else 0,
+                                                   _p(pooled), ld(pooled) if pooled is not None else 0,
+                                                   _p(stats), N, D, H, W, cout, _stream()), "conv3d_k3_small_fwd_finish")
 
 
 def conv3d_k3_small_bwd_finish(part, nstages, dx, unit=None, dgamma=None, dbeta=None, accumulate=False):

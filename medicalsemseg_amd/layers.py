@@ -644,17 +644,38 @@ class ResBlock:
         self.n1, self.n2 = InstNormAct(None, None, slope), InstNormAct(None, None, slope)
         self.n3 = InstNormAct(None, None, 1.0) if conv3_w is not None else None
 
+    @staticmethod
+    def _small_unit(conv, nrm, x, residual=None, out=None):
+        """conv + InstanceNorm (+ residual) + LeakyReLU on a small grid: split-K partials + ONE finish kernel (raw output,
+        statistics, normalise, residual, activation) -- csrc/conv3d_k3_small.hip; returns (activation, raw output, stats)"""
+        wp = conv.cache.get(conv.w, x.dtype, "fs", lambda: hip.pack_conv_k3(conv.w.detach(), x.dtype, cb=32))
+        part, ng = hip.conv3d_k3_small_partials(x, wp, conv.cin, conv.cout)
+        y = _empty_like_vol(x, conv.cout)
+        a = out if out is not None else _empty_like_vol(x, conv.cout)
+        stats = torch.empty(x.shape[0], conv.cout, 2, dtype=torch.float32, device=x.device)
+        hip.conv3d_k3_small_fwd_finish(part, ng, conv.b, nrm.gamma, nrm.beta, nrm.eps, nrm.slope, y, a, None, stats, residual)
+        return a, y, stats
+
     def fwd(self, x, out=None):
-        y1, s1 = self.c1.fwd(x, want_stats=True)
-        a1, s1 = self.n1.fwd(y1, stats=s1)
-        y2, s2 = self.c2.fwd(a1, want_stats=True)
+        # the 12^3 ... 3^3 levels (Swin-UNETR encoder4 / encoder10 / decoder5 / decoder4): both 3x3x3 convs on the split-K path
+        small = (not self.c1._gather(x.dtype) and hip.conv3d_k3_small_ok(x, self.c1.cin, self.c1.cout)
+                 and hip.conv3d_k3_small_ok(x, self.c2.cin, self.c2.cout))
+        if small:
+            a1, y1, s1 = self._small_unit(self.c1, self.n1, x)
+        else:
+            y1, s1 = self.c1.fwd(x, want_stats=True)
+            a1, s1 = self.n1.fwd(y1, stats=s1)
         if self.c3 is not None:
             y3, s3 = self.c3.fwd(x, want_stats=True)
             r, s3 = self.n3.fwd(y3, stats=s3)
         else:
             y3 = s3 = None
             r = x
-        o, s2 = self.n2.fwd(y2, out, residual=r, stats=s2)
+        if small:
+            o, y2, s2 = self._small_unit(self.c2, self.n2, a1, residual=r, out=out)
+        else:
+            y2, s2 = self.c2.fwd(a1, want_stats=True)
+            o, s2 = self.n2.fwd(y2, out, residual=r, stats=s2)
         return o, (x, y1, s1, a1, y2, s2, y3, s3, r, o)
 
     def bwd(self, saved, do, need_dx=True):

@@ -1206,6 +1206,66 @@ def test_eval_batchnorm_large_mean_small_variance():
     assert err < 5e-6
 
 
+@pytest.mark.parametrize("cin,cout,sp,N", [(64, 64, (3, 3, 3), 2), (128, 64, (6, 6, 6), 2), (96, 32, (12, 12, 12), 1), (768, 768, (3, 3, 3), 2)])
+def test_resblock_small_grid_forward_backward(monkeypatch, cin, cout, sp, N):
+    """layers.ResBlock (MONAI UnetResBlock: Swin-UNETR encoder4 / encoder10 / decoder5 / decoder4) on the 12^3 ... 3^3 grids:
+    both 3x3x3 convolutions as split-K partials + one finish kernel each (raw output, statistics, normalise, residual, LeakyReLU;
+    3^3 = one quarter-filled tile per sample) and the input gradients on the same path, against the tile kernels
+    (MSSEG_NO_K3_SMALL=1) and torch fp32 on the bf16-rounded operands"""
+    from medicalsemseg_amd import hip, layers
+    dev, dtype = _dev(), torch.bfloat16
+    x = gen(N, cin, *sp, seed=1)
+    do = gen(N, cout, *sp, seed=2)
+    mk = lambda *sh, seed: torch.nn.Parameter((gen(*sh, seed=seed) * (sh[1] * (27 if len(sh) == 5 and sh[2] == 3 else 1)) ** -0.5).to(dev))   # noqa: E731
+    w1, w2 = mk(cout, cin, 3, 3, 3, seed=3), mk(cout, cout, 3, 3, 3, seed=4)
+    w3 = mk(cout, cin, 1, 1, 1, seed=5) if cin != cout else None
+    xg, dog = cl(x, dtype, dev), cl(do, dtype, dev)
+    res = {}
+    for mode in ("small", "tile"):
+        if mode == "tile":
+            monkeypatch.setenv("MSSEG_NO_K3_SMALL", "1")
+        else:
+            monkeypatch.delenv("MSSEG_NO_K3_SMALL", raising=False)
+            assert hip.conv3d_k3_small_ok(xg, cin, cout)
+        for w in (w1, w2, w3):
+            if w is not None:
+                w.grad = None
+        blk = layers.ResBlock(w1, w2, w3)
+        layers.WGRAD_SIDE.begin(xg.device)
+        o, saved = blk.fwd(xg)
+        dx = blk.bwd(saved, dog, True)
+        layers.WGRAD_SIDE.join()
+        res[mode] = (o.float().clone(), dx.float().clone(), w1.grad.clone(), w2.grad.clone())
+    monkeypatch.delenv("MSSEG_NO_K3_SMALL", raising=False)
+    # torch reference
+    xr = x.to(dtype).float().requires_grad_(True)
+    w1r, w2r = w1.detach().cpu().to(dtype).float().requires_grad_(True), w2.detach().cpu().to(dtype).float().requires_grad_(True)
+    a1 = F.leaky_relu(F.instance_norm(F.conv3d(xr, w1r, padding=1)), 0.01)
+    y2 = F.instance_norm(F.conv3d(a1, w2r, padding=1))
+    r = xr if w3 is None else F.instance_norm(F.conv3d(xr, w3.detach().cpu().to(dtype).float()))
+    oref = F.leaky_relu(y2 + r, 0.01)
+    oref.backward(do.to(dtype).float())
+    errs = {}
+    for mode in ("small", "tile"):
+        o, dx, g1, g2 = res[mode]
+        so = float(oref.detach().abs().max())
+        eo = float((ncdhw(o).cpu() - oref.detach()).abs().max()) / so
+        ex = float((ncdhw(dx).cpu() - xr.grad).norm() / xr.grad.norm())    # rel. L2: single voxels flip with a LeakyReLU sign
+        e1 = float((g1.cpu() - w1r.grad).norm() / w1r.grad.norm())
+        e2 = float((g2.cpu() - w2r.grad).norm() / w2r.grad.norm())
+        print(f"[{mode}] out {eo:.3e} dx {ex:.3e} dW1 {e1:.3e} dW2 {e2:.3e}")
+        errs[mode] = (eo, ex, e1, e2)
+    # bf16 InstanceNorm over 27 ... 1728 voxels: the gradient error against fp32 is set by the statistics (the tile kernels
+    # show the same figures); the small path must not be worse than the tile path by more than a quarter
+    for es, et in zip(errs["small"], errs["tile"]):
+        assert es < 0.2 and es < 1.25 * et + 2e-3, (errs["small"], errs["tile"])
+    # the two kernel paths agree much closer than either does with fp32
+    o_s, dx_s = res["small"][0], res["small"][1]
+    o_t, dx_t = res["tile"][0], res["tile"][1]
+    assert float((o_s - o_t).abs().max()) / float(o_t.abs().max()) < 1.6e-2
+    assert float((dx_s - dx_t).norm() / dx_t.norm()) < 3e-2
+
+
 @pytest.mark.parametrize("cin,cmid,sp,N,pool", [(64, 128, (12, 12, 12), 2, True), (256, 128, (12, 12, 12), 1, False),
                                                 (128, 256, (6, 6, 6), 2, False), (32, 32, (6, 12, 6), 8, True),
                                                 (96, 64, (12, 6, 12), 3, True)])
