@@ -198,6 +198,17 @@ int msseg_deconv_k2s2_bwd_fused(const void* dy, long long lddy, const void* wp, 
                                 float* red, float* dgamma, float* dbeta, int accumulate, float* dbias, int dbias_accumulate,
                                 void* scratch, size_t scratch_bytes, int dtype, msseg_stream_t stream);
 
+/* Input gradient of ConvTranspose3d k2 s2 as ONE fp32 stage group in the layout of msseg_conv3d_k3_small_partials
+ * (part[Cin / 4][N*D*H*W][4], csrc/deconv_k2s2_gen.hip): msseg_conv3d_k3_small_bwd_finish(part, 1, ...) then stores dx, or
+ * runs the whole backward of the conv + InstanceNorm + LeakyReLU unit whose activation the transposed conv read (the deep
+ * UpCat levels of MONAI BasicUNet; /root/reference/models/segmentors/swin_unetr.py:93-128 transp_conv).  bf16; dy: fine
+ * [N, 2D, 2H, 2W, Cout]; wp: the backward image of msseg_pack_weights (M = Cin, K = 8 * Cout); part_bytes >= N*D*H*W*Cin*4.
+ * msseg_deconv_k2s2_bwd_partials_ok() == 1 for the channel counts with an instantiation (Cin % 32 == 0, Cout / 16 in
+ * {3, 4, 6, 8, 12, 24}). */
+int msseg_deconv_k2s2_bwd_partials_ok(int Cin, int Cout, int dtype);
+int msseg_deconv_k2s2_bwd_partials(const void* dy, long long lddy, const void* wp, float* part, size_t part_bytes, int N,
+                                   int D, int H, int W, int Cin, int Cout, int dtype, msseg_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradients (fp32 output in the torch parameter layout; deterministic two-stage reduction).

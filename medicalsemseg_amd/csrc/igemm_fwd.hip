@@ -1061,6 +1061,8 @@ int msseg_deconv_k2s2_fwd(const void* x, long long ldx, const void* wp, const fl
     if (NV < 1 || NV > 0x7fffffffLL / 8) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2: bad voxel count");
     if (msseg_deconv2_fast_eligible(dtype, Cin, Cout, x, ldx, y, ldy, bias))
         return msseg_deconv2_fwd_launch(x, ldx, wp, bias, y, ldy, N, D, H, W, Cin, Cout, (hipStream_t)stream);
+    if (msseg_deconv2g_fwd_eligible(dtype, Cin, Cout, x, ldx, y, ldy, bias))
+        return msseg_deconv2g_fwd_launch(x, ldx, wp, bias, y, ldy, N, D, H, W, Cin, Cout, (hipStream_t)stream);
     IgemmParams p{};
     p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy;
     p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = Cin; p.M = 8 * Cout;
@@ -1080,6 +1082,8 @@ int msseg_deconv_k2s2_bwd_data(const void* dy, long long lddy, const void* wp, v
     if (msseg_deconv2_fast_eligible(dtype, Cin, Cout, dx, lddx, dy, lddy, nullptr))
         return msseg_deconv2_bwd_launch(dy, lddy, wp, dx, lddx, N, D, H, W, Cin, Cout, nullptr, 0, nullptr, 0, nullptr, 0.f, 0.f,
                                         nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+    if (msseg_deconv2g_bwd_eligible(dtype, Cin, Cout, dx, lddx, dy, lddy))
+        return msseg_deconv2g_bwd_launch(dy, lddy, wp, dx, lddx, nullptr, N, D, H, W, Cin, Cout, (hipStream_t)stream);
     IgemmParams p{};
     p.x = dy; p.ldx = lddy; p.wp = wp; p.bias = nullptr; p.y = dx; p.ldy = lddx;
     p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.K = 8 * Cout; p.M = Cin;

@@ -88,6 +88,15 @@ int msseg_deconv2_bwd_launch(const void* dy, long long lddy, const void* wp, voi
                              int accumulate, float* dbias, int dbias_accumulate, void* scratch, size_t scratch_bytes,
                              hipStream_t stream);
 
+// ---- ConvTranspose3d k2 s2 for any channel count with an instantiation, output sliced over grid.y (deconv_k2s2_gen.hip) ----
+bool msseg_deconv2g_fwd_eligible(int dtype, int Cin, int Cout, const void* coarse, long long ldc, const void* fine,
+                                 long long ldf, const float* bias);
+int msseg_deconv2g_fwd_launch(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy, int N,
+                              int D, int H, int W, int Cin, int Cout, hipStream_t stream);
+bool msseg_deconv2g_bwd_eligible(int dtype, int Cin, int Cout, const void* coarse, long long ldc, const void* fine,
+                                 long long ldf);
+int msseg_deconv2g_bwd_launch(const void* dy, long long lddy, const void* wp, void* dx, long long lddx, float* part, int N,
+                              int D, int H, int W, int Cin, int Cout, hipStream_t stream);
 // ---- Linear / 1x1x1 conv on many tokens with few channels, register-resident weights (linear_regw.hip) ----
 bool msseg_linear_regw_eligible(int dtype, long long NV, int Cin, int Cout, const void* x, long long ldx, const void* y,
                                 long long ldy, const float* bias);

@@ -120,6 +120,8 @@ SIGNATURES = {
     "msseg_aug_crop_batch": ([_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp], _i),
     "msseg_sw_gather_batch": ([_vp, _ll, _vp, _ll, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
     "msseg_sw_blend_batch": ([_vp, _ll, _i, _vp, _vp, _ll, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_deconv_k2s2_bwd_partials_ok": ([_i, _i, _i], _i),
+    "msseg_deconv_k2s2_bwd_partials": ([_vp, _ll, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_conv3d_k3_small_ok": ([_i, _i, _i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_small_workspace_bytes": ([_i, _i, _i, _i, _i, _i], _sz),
     "msseg_conv3d_k3_small_stage_groups": ([_i, _i, _i, _i, _i, _i], _i),
@@ -549,6 +551,29 @@ def conv3d_k3_small_partials(x, wp, cin, cout):
                  lambda: _ck(lib().msseg_conv3d_k3_small_partials(_p(x), ld(x), _p(wp), _p(part), part.numel() * 4, N, D, H, W, cin,
                                                                   cout, _stream()), "conv3d_k3_small_partials"))
     return part, ng
+
+
+def deconv_k2s2_small_unit_ok(dx_shape, cin, cout, dtype) -> bool:
+    """can the input gradient of ConvTranspose3d k2 s2 (cin -> cout) for a coarse volume dx_shape = (N, D, H, W, cin) go out as a
+    partial block for conv3d_k3_small_bwd_finish (which then runs the receiving unit's whole InstanceNorm backward)?"""
+    if os.environ.get("MSSEG_NO_K3_SMALL") or dtype != torch.bfloat16 or len(dx_shape) != 5:
+        return False
+    N, D, H, W = dx_shape[:4]
+    return N <= 8 and D * H * W <= 2048 and bool(lib().msseg_deconv_k2s2_bwd_partials_ok(cin, cout, BF16))
+
+
+def deconv_k2s2_bwd_partials(dy, wp, cin, cout):
+    """fp32 partial block [cin / 4][N * D * H * W][4] (ONE stage group) of the input gradient of ConvTranspose3d k2 s2; dy: fine
+    [N, 2D, 2H, 2W, cout]; the buffer is the small-grid scratch: consume it (conv3d_k3_small_bwd_finish(part, 1, ...)) before
+    the next partials call on the stream"""
+    _need_gpu(dy, wp)
+    N, D, H, W = dy.shape[0], dy.shape[1] // 2, dy.shape[2] // 2, dy.shape[3] // 2
+    nv = N * D * H * W
+    part = _k3s_workspace(nv * cin * 4, dy.device)
+    TIMER.launch("deconv_k2s2_bwd_partials", 2.0 * nv * 8 * cin * cout, nv * (8 * cout * dy.element_size() + cin * 4) + 8 * cin * cout * 2,
+                 lambda: _ck(lib().msseg_deconv_k2s2_bwd_partials(_p(dy), ld(dy), _p(wp), _p(part), part.numel() * 4, N, D, H, W, cin,
+                                                                  cout, dt(dy), _stream()), "deconv_k2s2_bwd_partials"))
+    return part
 
 
 def conv3d_k3_small_fwd_finish(part, nstages, bias, gamma, beta, eps, slope, yraw, act, pooled, stats, residual=None):

@@ -522,6 +522,17 @@ class Deconv2:
         wp = self.cache.get(self.w, dtype, "d", lambda: hip.pack_deconv(self.w.detach(), dtype, bwd=True))
         dx = torch.empty_like(x, memory_format=torch.contiguous_format)
         db, dbacc = _grad_buf(self.b) if want_db else (None, False)
+        if next_norm is not None and hip.deconv_k2s2_small_unit_ok(tuple(x.shape), self.cin, self.cout, dtype):
+            # small grid (the deep UpCat levels): K-split input gradient as one fp32 block, then the small-grid finish kernel
+            # runs the receiving conv + InstanceNorm + LeakyReLU unit's whole backward -- 2 launches for the generic flat
+            # kernel with fused sums, its finalize and the apply pass (csrc/deconv_k2s2_gen.hip, conv3d_k3_small.hip)
+            nrm, yraw, stats, act = next_norm
+            part = hip.deconv_k2s2_bwd_partials(dy, wp, self.cin, self.cout)
+            dg, dbt, nacc = _norm_grad_bufs(nrm)
+            hip.conv3d_k3_small_bwd_finish(part, 1, dx, (yraw, stats, nrm.gamma, nrm.beta, nrm.eps, nrm.slope), dg, dbt, nacc)
+            if want_db:
+                hip.channel_sum(dy, db, dbacc)
+            return dx, APPLIED
         nn_ = None
         dg = dbt = None
         nacc = False

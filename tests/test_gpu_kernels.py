@@ -202,7 +202,11 @@ def test_conv3d_stem(cout, sp, N):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,sp", [(32, 32, (8, 8, 8)), (256, 128, (3, 3, 3)), (96, 48, (6, 6, 6)), (48, 48, (4, 6, 10)),
                                          # register-resident-weight kernels (bf16): ragged W segments, both channel counts
-                                         (64, 32, (6, 7, 9)), (32, 32, (5, 6, 20)), (64, 32, (3, 4, 33))])
+                                         (64, 32, (6, 7, 9)), (32, 32, (5, 6, 20)), (64, 32, (3, 4, 33)),
+                                         # sliced-output kernels (bf16, csrc/deconv_k2s2_gen.hip): Swin-UNETR's and the deep
+                                         # BasicUNet shapes, ragged W segments, one- and two-child slices
+                                         (48, 48, (3, 5, 19)), (96, 48, (2, 3, 17)), (128, 64, (3, 4, 7)), (192, 96, (3, 5, 7)),
+                                         (384, 192, (3, 3, 3)), (768, 384, (2, 3, 3)), (256, 128, (2, 3, 18))])
 def test_deconv_k2s2(dtype, cin, cout, sp):
     from medicalsemseg_amd.layers import Deconv2
     dev = _dev()
@@ -955,6 +959,48 @@ def test_deconv_bwd_fused_sums_and_bias(dtype, cin, cout, sp, N):
     assert float((dyraw.float() - dyraw_ref.float()).abs().max()) / sc < tol
     for a, bb, nm in ((ga.grad, g_ref, "dgamma"), (be.grad, b_ref, "dbeta"), (b.grad, db_ref, "dbias")):
         assert float((a - bb).abs().max()) / (float(bb.abs().max()) + 1e-6) < 5e-4, nm
+
+
+@pytest.mark.parametrize("cin,cout,sp,N", [(256, 128, (3, 6, 6), 2), (128, 64, (6, 6, 12), 2), (128, 64, (4, 5, 7), 3)])
+def test_deconv_bwd_small_unit(cin, cout, sp, N):
+    """deep UpCat levels (bf16): the transposed conv's input gradient as one fp32 block (csrc/deconv_k2s2_gen.hip) + the small-grid
+    finish kernel that runs the receiving conv + InstanceNorm + LeakyReLU unit's whole backward == input gradient, separate
+    InstanceNorm backward, separate channel sum"""
+    from medicalsemseg_amd import hip
+    from medicalsemseg_amd.layers import APPLIED, Deconv2, InstNormAct
+    dev = _dev()
+    dtype = torch.bfloat16
+    yraw = cl(gen(N, cin, *sp, seed=1) * 1.5 + 0.3, dtype, dev)
+    w = torch.nn.Parameter(gen(cin, cout, 2, 2, 2, seed=2, scale=cin ** -0.5).to(dev))
+    b = torch.nn.Parameter(gen(cout, seed=6).to(dev))
+    fine = tuple(2 * v for v in sp)
+    dy = cl(gen(N, cout, *fine, seed=3), dtype, dev)
+    ga = torch.nn.Parameter((gen(cin, seed=4) * 0.2 + 1).to(dev))
+    be = torch.nn.Parameter((gen(cin, seed=5) * 0.2).to(dev))
+    nrm = InstNormAct(ga, be, 0.1)
+    act, stats = nrm.fwd(yraw)
+    op = Deconv2(w, b)
+    w.requires_grad_(False)
+    assert hip.deconv_k2s2_small_unit_ok(tuple(act.shape), cin, cout, dtype)
+    wp = hip.pack_deconv(w.detach(), dtype, bwd=True)
+    dx_ref = torch.empty_like(act)
+    hip.deconv_k2s2_bwd_data(dy, wp, dx_ref, cin, cout)
+    # the sliced-output kernel against plain torch (bf16-rounded operands, fp32 accumulation)
+    xr = torch.zeros(N, cin, *sp, requires_grad=True)
+    F.conv_transpose3d(xr, w.detach().cpu().to(dtype).float(), None, stride=2).backward(ncdhw(dy).cpu().float())
+    assert float((ncdhw(dx_ref).cpu().float() - xr.grad).abs().max()) / float(xr.grad.abs().max()) < 1e-2
+    dyraw_ref = nrm.bwd(yraw, stats, act, dx_ref)
+    g_ref, b_ref = ga.grad.clone(), be.grad.clone()
+    ga.grad = be.grad = None
+    db_ref = dy.float().sum(dim=(0, 1, 2, 3))
+    dyraw, red = op.bwd(act, dy, True, next_norm=(nrm, yraw, stats, act))
+    assert red is APPLIED
+    sc = float(dyraw_ref.float().abs().max())
+    assert float((dyraw.float() - dyraw_ref.float()).abs().max()) / sc < 2e-2     # one bf16 rounding of da more / less
+    rel = float((dyraw.float() - dyraw_ref.float()).norm() / dyraw_ref.float().norm())
+    assert rel < 4e-3, rel
+    for a_, bb, nm in ((ga.grad, g_ref, "dgamma"), (be.grad, b_ref, "dbeta"), (b.grad, db_ref, "dbias")):
+        assert float((a_ - bb).abs().max()) / (float(bb.abs().max()) + 1e-6) < 2e-3, nm
 
 
 def test_postproc_kernels_bit_exact(golden_dir):
