@@ -585,6 +585,11 @@ int wg_check(const void* a, long long lda, const void* b, long long ldb, const v
 
 }  // namespace
 
+// one-pass weight gradient of ConvTranspose3d k2 s2 (linear_wgrad.hip)
+bool msseg_lwg_deconv_ok(int dtype, long long NV, int Cin, int Cout, const void* x, long long ldx, const void* dy, long long lddy);
+int msseg_lwg_deconv_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, int N, int D, int H, int W,
+                           int Cin, int Cout, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 extern "C" {
 
 size_t msseg_wgrad_workspace_bytes(int M, int T, int K) {
@@ -653,11 +658,11 @@ int msseg_conv3d_gather_wgrad(const void* x, long long ldx, const void* dy, long
     if (OD < 1 || OH < 1 || OW < 1 || NV > 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_gather_wgrad: bad shape");
     const int KT = k * k * k;
     if (msseg_stem_eligible(dtype, Cin, Cout, k, s, pd, ldx, lddy, dy) && (lddy % 8) == 0 &&
-        workspace_bytes >= (size_t)8 * 4096 * (Cout / 32)) {
+        workspace_bytes >= (size_t)8 * 4096 * ceil_div(Cout, 32)) {
         StemWgParams sp{};
         sp.x = x; sp.ldx = ldx; sp.dy = dy; sp.lddy = lddy; sp.N = N; sp.D = ID; sp.H = IH; sp.W = IW; sp.M = Cout;
         int gx = msseg_stem_wgrad_grid(sp);
-        const long long fit = (long long)(workspace_bytes / ((size_t)4096 * (Cout / 32)));
+        const long long fit = (long long)(workspace_bytes / ((size_t)4096 * ceil_div(Cout, 32)));
         if (gx > fit) gx = (int)(fit & ~7LL);
         sp.slabs = (float*)workspace;
         int rc = msseg_stem_wgrad_launch(sp, gx, (hipStream_t)stream);
@@ -665,7 +670,7 @@ int msseg_conv3d_gather_wgrad(const void* x, long long ldx, const void* dy, long
         ReduceParams rq{};
         rq.dw = dw; rq.M = Cout; rq.M0 = Cout; rq.T = 1; rq.K = KT; rq.K0 = 1;
         rq.s_m0 = KT; rq.s_k1 = 1; rq.s_k0 = KT; rq.accumulate = accumulate;
-        rq.slabs = sp.slabs; rq.mblks = Cout / 32; rq.kblks = 1; rq.nslots = gx; rq.cbw = 32;
+        rq.slabs = sp.slabs; rq.mblks = ceil_div(Cout, 32); rq.kblks = 1; rq.nslots = gx; rq.cbw = 32;
         return launch_reduce(rq, (hipStream_t)stream);
     }
     WgradParams p{};
@@ -689,6 +694,9 @@ int msseg_deconv_k2s2_wgrad(const void* x, long long ldx, const void* dy, long l
     const int esz = dtype == MSSEG_F32 ? 4 : 2;
     const long long NV = (long long)N * D * H * W;
     if (Cout % (16 / esz) || NV < 1 || NV > 0x7fffffffLL / 8) MSSEG_FAIL(MSSEG_EINVAL, "deconv_k2s2_wgrad: bad shape");
+    if (msseg_lwg_deconv_ok(dtype, NV, Cin, Cout, x, ldx, dy, lddy))   // one pass over whole rows (linear_wgrad.hip)
+        return msseg_lwg_deconv_wgrad(x, ldx, dy, lddy, dw, N, D, H, W, Cin, Cout, accumulate, workspace, workspace_bytes,
+                                      (hipStream_t)stream);
     WgradParams p{};
     p.pten = x; p.ldp = ldx; p.qten = dy; p.ldq = lddy;
     p.N = 1; p.D = 1; p.H = 1; p.W = (int)NV; p.M = Cin; p.K = 8 * Cout;

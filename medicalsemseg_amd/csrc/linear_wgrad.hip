@@ -34,6 +34,9 @@ struct LwgParams {
     float* part;                       // [slice][workgroup][ [k: NTQ*16][m: NTP*16] + bias [NTP*16] ] fp32
     long long NV;
     int M, K, mslices, kslices, nchunks;
+    // DCV (weight gradient of ConvTranspose3d k2 s2): dy is the FINE tensor [N, 2D, 2H, 2W, cout]; the row of coarse token t is
+    // the 8 child rows (m = abc * cout + co), gathered while staging
+    int D, H, W, cout;
 };
 
 MSSEG_DEVFN bf16x4_t lds_tr_read(const unsigned char* p) {
@@ -46,7 +49,7 @@ MSSEG_DEVFN u32x4_t tr_frag(const unsigned char* base, int r0, int r1) {
     return __builtin_bit_cast(u32x4_t, f);
 }
 
-template <int NTP, int NTQ>
+template <int NTP, int NTQ, bool DCV = false>
 __global__ __launch_bounds__(LW_THREADS, 1) void lwg_kernel(const LwgParams p) {
     constexpr int NBP = (NTP + 1) / 2, NBQ = (NTQ + 1) / 2;       // 32-channel block images
     constexpr int CHP = NTP * 2, CHQ = NTQ * 2;                   // 16-byte pieces per row of the slice
@@ -67,7 +70,20 @@ __global__ __launch_bounds__(LW_THREADS, 1) void lwg_kernel(const LwgParams p) {
     // ---- staging: piece i of the chunk = (row i / CH, 16-byte piece i % CH of the slice's part of the row); the offsets are
     // recomputed per chunk (constant divisions) instead of held in 3 registers per piece: the accumulators need the room
     u32x4_t sp[NLP], sq[NLQ];
-    auto fetch = [&](int chunk) {
+    __shared__ unsigned fbase[2][DCV ? TT : 1];   // DCV: fine voxel (2d, 2h, 2w) of the chunk's tokens (fine voxel count < 2^31)
+    auto fill_table = [&](int chunk, int sel) {
+        if constexpr (DCV) {
+            if (tid < TT) {
+                unsigned t = (unsigned)chunk * (unsigned)TT + (unsigned)tid;
+                if ((long long)t >= p.NV) t = 0;
+                const unsigned w = t % (unsigned)p.W; t /= (unsigned)p.W;
+                const unsigned h = t % (unsigned)p.H; t /= (unsigned)p.H;
+                const unsigned d = t % (unsigned)p.D, n = t / (unsigned)p.D;
+                fbase[sel][tid] = ((n * 2u * p.D + 2u * d) * 2u * p.H + 2u * h) * 2u * p.W + 2u * w;
+            }
+        }
+    };
+    auto fetch = [&](int chunk, int tsel) {
         const long long t0 = (long long)chunk * TT;
         const int rows = (p.NV - t0) < TT ? (int)(p.NV - t0) : TT;
         const unsigned char* pb = pg + t0 * p.lddy * 2;
@@ -75,7 +91,17 @@ __global__ __launch_bounds__(LW_THREADS, 1) void lwg_kernel(const LwgParams p) {
 #pragma unroll
         for (int it = 0; it < NLP; ++it) {
             const int i = tid + it * LW_THREADS, row = i / CHP, c = i - row * CHP;
-            sp[it] = row < rows ? *(const u32x4_t*)(pb + (unsigned)(row * (int)p.lddy * 2 + c * 16)) : u32x4_t{0u, 0u, 0u, 0u};
+            if constexpr (DCV) {
+                // piece c of the slice = channels (ms * NTP * 2 + c) * 8 .. of the gathered row: child abc, channel co; the
+                // row's fine base voxel comes from the table the first 128 threads filled for this chunk
+                const unsigned ch = (unsigned)(ms * NTP * 2 + c) * 8u;
+                const unsigned abc = ch / (unsigned)p.cout, co = ch - abc * (unsigned)p.cout;
+                const unsigned fv = fbase[tsel][row < TT ? row : 0] + ((abc >> 2) * 2u * p.H + ((abc >> 1) & 1u)) * 2u * p.W + (abc & 1u);
+                sp[it] = row < rows ? *(const u32x4_t*)((const unsigned char*)p.dy + ((unsigned long long)fv * (unsigned)p.lddy + co) * 2)
+                                    : u32x4_t{0u, 0u, 0u, 0u};
+            } else {
+                sp[it] = row < rows ? *(const u32x4_t*)(pb + (unsigned)(row * (int)p.lddy * 2 + c * 16)) : u32x4_t{0u, 0u, 0u, 0u};
+            }
         }
 #pragma unroll
         for (int it = 0; it < NLQ; ++it) {
@@ -112,12 +138,20 @@ __global__ __launch_bounds__(LW_THREADS, 1) void lwg_kernel(const LwgParams p) {
     }
     const u32x4_t ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // bf16 1.0 x 8
 
-    if ((int)blockIdx.x < p.nchunks) fetch(blockIdx.x);
+    if constexpr (DCV) {
+        fill_table(blockIdx.x, 0);
+        __syncthreads();
+    }
+    if ((int)blockIdx.x < p.nchunks) fetch(blockIdx.x, 0);
+    int tsel = 0;
     for (int chunk = blockIdx.x; chunk < p.nchunks; chunk += gridDim.x) {
         __syncthreads();                 // the previous chunk's fragment reads are done
         commit();
+        tsel ^= 1;
+        fill_table(chunk + gridDim.x, tsel);   // read by the fetch behind the next barrier; the other half is still the table of
+                                               // the pieces in flight ... which were fetched before this point
         __syncthreads();
-        if (chunk + (int)gridDim.x < p.nchunks) fetch(chunk + gridDim.x);
+        if (chunk + (int)gridDim.x < p.nchunks) fetch(chunk + gridDim.x, tsel);
         u32x4_t pf[NTP], qf[NTQ];
 #pragma unroll
         for (int a = 0; a < NTP; ++a) pf[a] = tr_frag(ldsP + (a >> 1) * BLK_BYTES, trow[0] + (a & 1) * 32, trow[1] + (a & 1) * 32);
@@ -156,6 +190,7 @@ struct LwgRedParams {
     const float* part;
     float* dw; float* db;
     int M, K, ntp16, ntq16, mslices, kslices, nwg, acc_w, acc_b;
+    int dcv_cout;   // > 0: m = abc * cout + co of a transposed conv: dw in the torch layout [K = Cin][cout][8]
 };
 
 // 256 threads = 32 outputs x 8 groups: a thread adds every 8th workgroup's partial (8 loads in flight), the 8 group sums are
@@ -192,8 +227,15 @@ __global__ __launch_bounds__(256) void lwg_reduce_kernel(const LwgRedParams p) {
             float tot = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) tot += gs[j][ol];
-            if (bias) p.db[m] = p.acc_b ? p.db[m] + tot : tot;
-            else p.dw[i] = p.acc_w ? p.dw[i] + tot : tot;
+            if (bias) {
+                p.db[m] = p.acc_b ? p.db[m] + tot : tot;
+            } else if (p.dcv_cout > 0) {
+                const int k = i - m * p.K, abc = m / p.dcv_cout, co = m - abc * p.dcv_cout;
+                float* o = p.dw + ((long long)k * p.dcv_cout + co) * 8 + abc;
+                *o = p.acc_w ? *o + tot : tot;
+            } else {
+                p.dw[i] = p.acc_w ? p.dw[i] + tot : tot;
+            }
         }
         __syncthreads();
     }
@@ -202,6 +244,19 @@ __global__ __launch_bounds__(256) void lwg_reduce_kernel(const LwgRedParams p) {
 // slice shapes with an instantiation, in order of preference (most output tiles per workgroup first)
 struct Shape { int ntp, ntq; };
 constexpr Shape kShapes[] = {{12, 3}, {3, 12}, {6, 6}, {9, 3}, {3, 9}, {6, 3}, {3, 6}, {3, 3}};
+// transposed convs: 8 * Cout / 16 is a multiple of 4, so a multiple of 3 is one of 12.  Measured (tools/bench_deconv.py, B = 2):
+// 48 -> 48 on 221 k coarse voxels 96 -> 63 us against the generic flat kernel, but 64 -> 32 on 27 k voxels 18 -> 28 us and
+// 128 -> 64 on 3.5 k 14 -> 21 us (power-of-two shapes {8, 4} / {8, 2}, since removed): with a few chunks per workgroup the
+// partial blocks and their reduction cost more than the flat kernel's re-reads.  Only the 48-multiples on large grids come here.
+constexpr Shape kShapesDcv[] = {{12, 3}};
+
+bool pick_shape_dcv(int M, int K, Shape* out) {
+    if (M % 16 || K % 16) return false;
+    const int tm = M / 16, tk = K / 16;
+    for (const Shape& s : kShapesDcv)
+        if (tm % s.ntp == 0 && tk % s.ntq == 0) { *out = s; return true; }
+    return false;
+}
 
 bool pick_shape(int M, int K, Shape* out) {
     if (M % 16 || K % 16) return false;
@@ -211,21 +266,68 @@ bool pick_shape(int M, int K, Shape* out) {
     return false;
 }
 
-template <int NTP, int NTQ> int launch_lwg(const LwgParams& p, int gx, hipStream_t stream) {
+template <int NTP, int NTQ, bool DCV = false> int launch_lwg(const LwgParams& p, int gx, hipStream_t stream) {
     constexpr int NBP = (NTP + 1) / 2, NBQ = (NTQ + 1) / 2;
     constexpr int PART = NTP * 16 * NTQ * 16 + NTP * 16;
     constexpr int lds = (NBP + NBQ) * BLK_BYTES > 4 * PART * 4 ? (NBP + NBQ) * BLK_BYTES : 4 * PART * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = lwg_kernel<NTP, NTQ>;
+    auto kern = lwg_kernel<NTP, NTQ, DCV>;
     static msseg_lds_attr_once attr;
     if (!attr.ensure((const void*)kern, lds)) MSSEG_FAIL(MSSEG_ELAUNCH, "linear_wgrad: cannot set dynamic LDS size %d", lds);
-    MSSEG_KTIMED("lwg_kernel", stream,
+    MSSEG_KTIMED(DCV ? "lwg_kernel<deconv>" : "lwg_kernel", stream,
                  hipLaunchKernelGGL(kern, dim3(gx, p.mslices * p.kslices), dim3(LW_THREADS), lds, stream, p));
     MSSEG_CHECK_LAUNCH("linear_wgrad");
     return MSSEG_OK;
 }
 
 }  // namespace
+
+// ---- weight gradient of ConvTranspose3d k2 s2 on the one-pass kernel (called by msseg_deconv_k2s2_wgrad, igemm_wgrad.hip):
+// dw[Cin][Cout][2][2][2] (+)= sum over coarse voxels of x[v][ci] * dy[child abc of v][co].  The generic flat kernel gave every
+// (32 x 32) block pair of the [Cin][8 * Cout] matrix its own workgroup column, each walking all voxels (34 us per BasicUNet
+// layer, 64 us per Swin-UNETR layer); here a workgroup reads whole rows -- the coarse row and the 8 child rows it gathers.
+bool msseg_lwg_deconv_ok(int dtype, long long NV, int Cin, int Cout, const void* x, long long ldx, const void* dy, long long lddy) {
+    static const bool off = getenv("MSSEG_NO_LINEAR_WGRAD") != nullptr || getenv("MSSEG_NO_DECONV_LWG") != nullptr;   // A/B switch
+    Shape s;
+    if (off || dtype != MSSEG_BF16 || NV < 100000 || NV > 0x7fffffffLL / 8 || Cout % 8) return false;
+    if ((((uintptr_t)x | (uintptr_t)dy) & 15) || (ldx % 8) || (lddy % 8) || ldx < Cin || lddy < Cout) return false;
+    return pick_shape_dcv(8 * Cout, Cin, &s);
+}
+
+int msseg_lwg_deconv_wgrad(const void* x, long long ldx, const void* dy, long long lddy, float* dw, int N, int D, int H, int W,
+                           int Cin, int Cout, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    Shape s;
+    if (!pick_shape_dcv(8 * Cout, Cin, &s)) MSSEG_FAIL(MSSEG_EINVAL, "deconv wgrad: shape %d -> %d has no instantiation", Cin, Cout);
+    if ((uintptr_t)workspace & 15) MSSEG_FAIL(MSSEG_EINVAL, "deconv wgrad: workspace alignment");
+    LwgParams p{};
+    p.x = x; p.ldx = ldx; p.dy = dy; p.lddy = lddy; p.NV = (long long)N * D * H * W; p.M = 8 * Cout; p.K = Cin;
+    p.D = D; p.H = H; p.W = W; p.cout = Cout;
+    p.mslices = p.M / (s.ntp * 16); p.kslices = Cin / (s.ntq * 16);
+    p.nchunks = (int)((p.NV + TT - 1) / TT);
+    const int slices = p.mslices * p.kslices;
+    const size_t part_bytes = (size_t)(s.ntp * 16 * s.ntq * 16 + s.ntp * 16) * 4;
+    int gx = msseg_num_cus() / slices;
+    if (gx < 1) gx = 1;
+    if (gx > (p.nchunks + 1) / 2) gx = (p.nchunks + 1) / 2;
+    if (gx < 1) gx = 1;
+    const size_t fit = workspace_bytes / (part_bytes * slices);
+    if (fit < 1) MSSEG_FAIL(MSSEG_EWORKSPACE, "deconv wgrad: workspace %zu B too small (need >= %zu)", workspace_bytes, part_bytes * slices);
+    if ((size_t)gx > fit) gx = (int)fit;
+    p.part = (float*)workspace;
+    int rc = MSSEG_EINVAL;
+    switch (s.ntp * 100 + s.ntq) {
+        case 1203: rc = launch_lwg<12, 3, true>(p, gx, stream); break;
+    }
+    if (rc) return rc;
+    LwgRedParams r{};
+    r.part = p.part; r.dw = dw; r.db = nullptr; r.M = p.M; r.K = Cin; r.ntp16 = s.ntp * 16; r.ntq16 = s.ntq * 16;
+    r.mslices = p.mslices; r.kslices = p.kslices; r.nwg = gx; r.acc_w = accumulate; r.acc_b = 0; r.dcv_cout = Cout;
+    int rb = (p.M * Cin + 31) / 32;
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(lwg_reduce_kernel, dim3(rb), dim3(256), 0, stream, r);
+    MSSEG_CHECK_LAUNCH("deconv_wgrad_reduce");
+    return MSSEG_OK;
+}
 
 extern "C" {
 

@@ -58,10 +58,12 @@ struct Sched {
 // forward
 // ------------------------------------------------------------------------------------------------------------
 constexpr int F_THREADS = 512;
-constexpr int F_STAT_FLOATS = 8 * MSSEG_STATS_NMAX * 32 * 2;
-
-template <int STATS>
+// JT = 16-wide cout tiles per cout block: 2 (32-wide blocks, BasicUNet's 1 -> 32 stem) or 3 (48-wide: the 1 -> 48 first conv of
+// Swin-UNETR's encoder1 UnetResBlock, /root/reference/models/segmentors/swin_unetr.py:73-81)
+template <int STATS, int JT>
 __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p) {
+    constexpr int CBW = JT * 16;
+    constexpr int F_STAT_FLOATS = 8 * MSSEG_STATS_NMAX * CBW * 2;
     __shared__ __attribute__((aligned(16))) unsigned short halo[2][HV + 8];
     __shared__ float ldsS[STATS ? F_STAT_FLOATS : 1];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -74,14 +76,15 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
     sc.init(p.N, p.D, p.H, p.W);
 
     // weights: A operand fragments straight from the packed image [q][cout 32][16 B] of this cout block
-    u32x4_t wf[2];
+    u32x4_t wf[JT];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-        wf[jt] = *(const u32x4_t*)((const unsigned char*)p.wp + (long long)coutblk * (4 * 32 * 16) + (q * 32 + jt * 16 + r) * 16);
-    f32x4_t bv[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-    if (p.bias) {
+    for (int jt = 0; jt < JT; ++jt)
+        wf[jt] = *(const u32x4_t*)((const unsigned char*)p.wp + (long long)coutblk * (4 * CBW * 16) + (q * CBW + jt * 16 + r) * 16);
+    f32x4_t bv[JT];
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) bv[jt] = *(const f32x4_t*)(p.bias + coutblk * 32 + jt * 16 + q * 4);
+    for (int jt = 0; jt < JT; ++jt) {
+        bv[jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv[jt] = *(const f32x4_t*)(p.bias + coutblk * CBW + jt * 16 + q * 4);
     }
     // taps 8q .. 8q+7 of this lane's k group: element offsets in the halo image (tap >= 27: masked)
     int toff[8];
@@ -93,17 +96,17 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
     if (STATS) {
         for (int i = tid; i < F_STAT_FLOATS; i += F_THREADS) ldsS[i] = 0.f;
     }
-    float s1[2][4], s2[2][4];
+    float s1[JT][4], s2[JT][4];
     int s_n = -1;
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s1[jt][e] = s2[jt][e] = 0.f;
     auto flush_stats = [&]() {
         if (s_n < 0) return;
-        float* slot = ldsS + ((wave * MSSEG_STATS_NMAX + s_n) * 32) * 2;
+        float* slot = ldsS + ((wave * MSSEG_STATS_NMAX + s_n) * CBW) * 2;
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float a = s1[jt][e], b = s2[jt][e];
@@ -171,12 +174,12 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
             const bool ok = d < p.D && h < p.H && w < p.W;
             const long long vox = (((long long)tc.n * p.D + d) * p.H + h) * p.W + w;
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
+            for (int jt = 0; jt < JT; ++jt) {
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
                 mma_chunk<bf16_t>(acc, wf[jt], xf);
                 const f32x4_t o = acc + bv[jt];
                 const bf16x4_t ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
-                if (ok) *(bf16x4_t*)(yg + vox * p.ldy + coutblk * 32 + jt * 16 + q * 4) = ob;
+                if (ok) *(bf16x4_t*)(yg + vox * p.ldy + coutblk * CBW + jt * 16 + q * 4) = ob;
                 if constexpr (STATS != 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -193,12 +196,12 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
     if constexpr (STATS != 0) {
         flush_stats();
         __syncthreads();
-        const int PN = p.N * 32 * 2;
+        const int PN = p.N * CBW * 2;
         float* wsp = p.stats_ws + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * PN;
         for (int i = tid; i < PN; i += F_THREADS) {
             float s = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < 8; ++wv) s += ldsS[wv * MSSEG_STATS_NMAX * 64 + i];
+            for (int wv = 0; wv < 8; ++wv) s += ldsS[wv * MSSEG_STATS_NMAX * CBW * 2 + i];
             wsp[i] = s;
         }
     }
@@ -250,9 +253,11 @@ __global__ __launch_bounds__(W_THREADS) void stem_wgrad_kernel(const StemWgParam
         const unsigned char* pb = dyg + pvox * p.lddy * 2;
         const bool full = tc.d0 + TD <= p.D && tc.h0 + TH <= p.H && tc.w0 + TW <= p.W;
         const unsigned char* zsrc = (const unsigned char*)&g_stem_zero_chunk;
+        const bool ch_ok = mblk * 32 + (lane & 3) * 8 < p.M;   // 48 couts: the second block's upper half is padding
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned char* src = pb + p_off[j];
+            if (!ch_ok) src = zsrc;
             if (!full) {
                 const int tv = (wave + 4 * j) * 16 + (lane >> 2);
                 const int td = tv / (TH * TW), th = (tv / TW) % TH, tw = tv % TW;
@@ -340,23 +345,29 @@ __global__ __launch_bounds__(W_THREADS) void stem_wgrad_kernel(const StemWgParam
 
 bool msseg_stem_eligible(int dtype, int Cin, int Cout, int k, int s, int pd, long long ldx, long long ldy, const void* y) {
     static const bool off = getenv("MSSEG_NO_STEM") != nullptr;
-    return !off && dtype == MSSEG_BF16 && Cin == 1 && k == 3 && s == 1 && pd == 1 && Cout % 32 == 0 && Cout <= 256 &&
+    return !off && dtype == MSSEG_BF16 && Cin == 1 && k == 3 && s == 1 && pd == 1 && (Cout % 32 == 0 || Cout % 48 == 0) && Cout <= 256 &&
            ldx >= 1 && (ldy % 4) == 0 && (((uintptr_t)y) & 7) == 0;
 }
 
 int msseg_stem_fwd_launch(const StemParams& p, hipStream_t stream) {
-    const int ncb = p.M / 32;
+    const int cbw = (p.M % 32 == 0) ? 32 : 48;   // = msseg_cout_block(M): the block width of the packed image
+    const int ncb = p.M / cbw;
     const int tiles = p.N * ceil_div(p.D, TD) * ceil_div(p.H, TH) * ceil_div(p.W, TW);
     int gx = msseg_num_cus() * 2 / ncb;
     gx &= ~7;
     if (gx < 8) gx = 8;
     if (gx > tiles) gx = tiles;
-    if (p.stats) hipLaunchKernelGGL(stem_fwd_kernel<1>, dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
-    else hipLaunchKernelGGL(stem_fwd_kernel<0>, dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
+    if (cbw == 32) {
+        if (p.stats) hipLaunchKernelGGL((stem_fwd_kernel<1, 2>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL((stem_fwd_kernel<0, 2>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
+    } else {
+        if (p.stats) hipLaunchKernelGGL((stem_fwd_kernel<1, 3>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL((stem_fwd_kernel<0, 3>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
+    }
     MSSEG_CHECK_LAUNCH("stem_fwd");
     if (p.stats) {
         K3FinParams f{};
-        f.ws = p.stats_ws; f.R = gx; f.N = p.N; f.coutb = 32; f.M = p.M; f.stats = p.stats;
+        f.ws = p.stats_ws; f.R = gx; f.N = p.N; f.coutb = cbw; f.M = p.M; f.stats = p.stats;
         return msseg_k3_stats_finalize(f, ncb, stream);
     }
     return MSSEG_OK;
@@ -364,7 +375,7 @@ int msseg_stem_fwd_launch(const StemParams& p, hipStream_t stream) {
 
 int msseg_stem_wgrad_grid(const StemWgParams& p) {
     const int tiles = p.N * ceil_div(p.D, TD) * ceil_div(p.H, TH) * ceil_div(p.W, TW);
-    int gx = msseg_num_cus() * 2 / (p.M / 32);
+    int gx = msseg_num_cus() * 2 / ceil_div(p.M, 32);
     gx &= ~7;
     if (gx < 8) gx = 8;
     if (gx > tiles) gx = tiles;
@@ -375,7 +386,7 @@ int msseg_stem_wgrad_launch(const StemWgParams& p, int gx, hipStream_t stream) {
     const int lds = 2 * (P_BYTES + 3 * XS_ELEMS * 2 + 64);
     static msseg_lds_attr_once attr;
     if (!attr.ensure((const void*)stem_wgrad_kernel, lds)) MSSEG_FAIL(MSSEG_ELAUNCH, "stem_wgrad: cannot set dynamic LDS size %d", lds);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(gx, p.M / 32), dim3(W_THREADS), lds, stream, p);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(gx, ceil_div(p.M, 32)), dim3(W_THREADS), lds, stream, p);
     MSSEG_CHECK_LAUNCH("stem_wgrad");
     return MSSEG_OK;
 }

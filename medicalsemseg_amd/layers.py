@@ -253,7 +253,8 @@ class Conv3:
         stats = None
         if self._gather(dtype):
             wp = self.cache.get(self.w, dtype, "g", lambda: hip.pack_conv_gather(self.w.detach(), dtype))
-            if self.cin == 1 and dtype == torch.bfloat16 and self.cout % 32 == 0 and self.cout <= 256:
+            if (self.cin == 1 and dtype == torch.bfloat16 and (self.cout % 32 == 0 or self.cout % 48 == 0) and self.cout <= 256
+                    and not os.environ.get("MSSEG_NO_STEM")):
                 # the one-channel stem: dedicated kernel with the statistics fused
                 if want_stats and x.shape[0] <= 8:
                     stats = torch.empty(x.shape[0], self.cout, 2, dtype=torch.float32, device=x.device)

@@ -158,7 +158,9 @@ def test_conv3d_gather(dtype, cin, cout, k, s, p, sp):
     check(dw, wr.grad, dtype, "gather wgrad")
 
 
-@pytest.mark.parametrize("cout,sp,N", [(32, (16, 16, 16), 2), (64, (10, 13, 21), 3), (32, (33, 20, 48), 2)])
+@pytest.mark.parametrize("cout,sp,N", [(32, (16, 16, 16), 2), (64, (10, 13, 21), 3), (32, (33, 20, 48), 2),
+                                       # 48-wide cout blocks: Swin-UNETR's 1 -> 48 first conv
+                                       (48, (16, 16, 16), 2), (48, (9, 14, 35), 3), (96, (8, 8, 16), 1)])
 def test_conv3d_stem(cout, sp, N):
     """one-input-channel stem kernels (bf16): forward + fused InstanceNorm statistics + weight gradient, on grids that
     are not tile multiples"""
@@ -959,6 +961,25 @@ def test_deconv_bwd_fused_sums_and_bias(dtype, cin, cout, sp, N):
     assert float((dyraw.float() - dyraw_ref.float()).abs().max()) / sc < tol
     for a, bb, nm in ((ga.grad, g_ref, "dgamma"), (be.grad, b_ref, "dbeta"), (b.grad, db_ref, "dbias")):
         assert float((a - bb).abs().max()) / (float(bb.abs().max()) + 1e-6) < 5e-4, nm
+
+
+def test_deconv_wgrad_large_grid_one_pass():
+    """Swin-UNETR's 48 -> 48 transposed conv on a grid of > 100 k coarse voxels: the weight gradient takes the one-pass kernel
+    with the child-row gather (csrc/linear_wgrad.hip, DCV) -- against the fp32 contraction of the same bf16 operands"""
+    from medicalsemseg_amd import hip
+    dev = _dev()
+    cin = cout = 48
+    N, sp = 2, (40, 41, 32)
+    x = (torch.randn(N, *sp, cin, device=dev) * 0.5).to(torch.bfloat16)
+    dy = (torch.randn(N, *(2 * v for v in sp), cout, device=dev) * 0.5).to(torch.bfloat16)
+    dw = torch.full((cin, cout, 2, 2, 2), float("nan"), device=dev)
+    hip.deconv_k2s2_wgrad(x, dy, dw, cin, cout)
+    dyv = dy.float().view(N, sp[0], 2, sp[1], 2, sp[2], 2, cout)
+    ref = torch.einsum("ndhwi,ndahbwco->ioabc", x.float(), dyv)
+    assert float((dw - ref).abs().max()) / float(ref.abs().max()) < 2e-4
+    dw2 = dw.clone()
+    hip.deconv_k2s2_wgrad(x, dy, dw2, cin, cout, True)
+    assert float((dw2 - 2 * ref).abs().max()) / float(ref.abs().max()) < 4e-4
 
 
 @pytest.mark.parametrize("cin,cout,sp,N", [(256, 128, (3, 6, 6), 2), (128, 64, (6, 6, 12), 2), (128, 64, (4, 5, 7), 3)])
