@@ -1020,7 +1020,7 @@ int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const 
     if (msseg_stem_eligible(dtype, Cin, Cout, k, s, pd, ldx, ldy, y)) {
         StemParams sp{};
         sp.x = x; sp.ldx = ldx; sp.wp = wp; sp.bias = bias; sp.y = y; sp.ldy = ldy;
-        sp.N = N; sp.D = ID; sp.H = IH; sp.W = IW; sp.M = Cout;
+        sp.N = N; sp.D = ID; sp.H = IH; sp.W = IW; sp.M = Cout; sp.taps = k == 1 ? 1 : 27;
         return msseg_stem_fwd_launch(sp, (hipStream_t)stream);
     }
     IgemmParams p{};

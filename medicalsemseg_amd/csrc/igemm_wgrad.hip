@@ -670,7 +670,8 @@ int msseg_conv3d_gather_wgrad(const void* x, long long ldx, const void* dy, long
         ReduceParams rq{};
         rq.dw = dw; rq.M = Cout; rq.M0 = Cout; rq.T = 1; rq.K = KT; rq.K0 = 1;
         rq.s_m0 = KT; rq.s_k1 = 1; rq.s_k0 = KT; rq.accumulate = accumulate;
-        rq.slabs = sp.slabs; rq.mblks = ceil_div(Cout, 32); rq.kblks = 1; rq.nslots = gx; rq.cbw = 32;
+        // k == 1 (the 1x1x1 conv of a one-channel volume): the slabs hold all 27 taps, the gradient is the centre one
+        rq.slabs = sp.slabs + (k == 1 ? 13 : 0); rq.mblks = ceil_div(Cout, 32); rq.kblks = 1; rq.nslots = gx; rq.cbw = 32;
         return launch_reduce(rq, (hipStream_t)stream);
     }
     WgradParams p{};

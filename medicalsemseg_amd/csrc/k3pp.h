@@ -65,6 +65,7 @@ struct StemParams {
     void* y; long long ldy;
     int N, D, H, W, M;
     float* stats; float* stats_ws;    // optional fused statistics (partial rows -> msseg_k3_stats_finalize)
+    int taps;                         // 27 (or 0): conv k3 p1; 1: the 1x1x1 conv of a one-channel volume (image with K = 1)
 };
 struct StemWgParams {
     const void* x; long long ldx;

@@ -87,11 +87,12 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
         if (p.bias) bv[jt] = *(const f32x4_t*)(p.bias + coutblk * CBW + jt * 16 + q * 4);
     }
     // taps 8q .. 8q+7 of this lane's k group: element offsets in the halo image (tap >= 27: masked)
+    const int ntaps = p.taps == 1 ? 1 : 27;   // 1: the 1x1x1 conv (UnetResBlock's conv3 on the one-channel input): centre voxel only
     int toff[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = q * 8 + j;
-        toff[j] = (k < 27) ? ((k / 9) * PH + ((k / 3) % 3)) * PW + (k % 3) : 0;
+        toff[j] = ntaps == 1 ? (PH + 1) * PW + 1 : ((k < 27) ? ((k / 9) * PH + ((k / 3) % 3)) * PW + (k % 3) : 0);
     }
     if (STATS) {
         for (int i = tid; i < F_STAT_FLOATS; i += F_THREADS) ldsS[i] = 0.f;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
             u32x4_t xf;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned lo = (q * 8 + 2 * j < 27) ? v[2 * j] : 0u, hi = (q * 8 + 2 * j + 1 < 27) ? v[2 * j + 1] : 0u;
+                const unsigned lo = (q * 8 + 2 * j < ntaps) ? v[2 * j] : 0u, hi = (q * 8 + 2 * j + 1 < ntaps) ? v[2 * j + 1] : 0u;
                 xf[j] = lo | (hi << 16);
             }
             const int d = tc.d0 + dw, h = tc.h0 + hrow, w = tc.w0 + r;
@@ -345,7 +346,8 @@ __global__ __launch_bounds__(W_THREADS) void stem_wgrad_kernel(const StemWgParam
 
 bool msseg_stem_eligible(int dtype, int Cin, int Cout, int k, int s, int pd, long long ldx, long long ldy, const void* y) {
     static const bool off = getenv("MSSEG_NO_STEM") != nullptr;
-    return !off && dtype == MSSEG_BF16 && Cin == 1 && k == 3 && s == 1 && pd == 1 && (Cout % 32 == 0 || Cout % 48 == 0) && Cout <= 256 &&
+    return !off && dtype == MSSEG_BF16 && Cin == 1 && ((k == 3 && pd == 1) || (k == 1 && pd == 0)) && s == 1 &&
+           (Cout % 32 == 0 || Cout % 48 == 0) && Cout <= 256 &&
            ldx >= 1 && (ldy % 4) == 0 && (((uintptr_t)y) & 7) == 0;
 }
 

@@ -279,6 +279,12 @@ class Conv3:
             return 0
         if self.cin == 96 and hip.lib().msseg_conv3d_k3_kernel(*vol, 48, self.cout, hip.BF16) == 4:
             return 48
+        # inference only (sliding window, 8 windows per launch): the 64- / 128-input-channel convs of the 24^3 level as 2 / 4
+        # launches of the 32-channel ping-pong kernel on channel slices of the input (the generic kernel runs them at 250 TFLOP/s:
+        # chains of 32-channel stages on 4x4x8 tiles); in training that grid (batch 2) is too small for the ping-pong kernel
+        if (not torch.is_grad_enabled() and self.cin in (64, 128) and self.cout % 32 == 0 and not os.environ.get("MSSEG_NO_KSPLIT_INFER")
+                and hip.lib().msseg_conv3d_k3_kernel(*vol, 32, self.cout, hip.BF16) == 3):
+            return 32
         # 64 -> 2 x 32 on the 32-channel ping-pong kernel (BasicUNet's UpCat convs in TRAINING, where the concat buffer exists
         # anyway for the weight gradient) measured neutral: 4.031 vs 4.026 ms per step -- the second launch's read-back of
         # the stored sums costs what the faster kernel gains; the inference forward (fwd_split: no concat buffer) keeps it
@@ -291,13 +297,16 @@ class Conv3:
         sum is rounded to bf16 once more than there.  Returns (y, stats)."""
         dtype, vol = x.dtype, tuple(x.shape[:4])
         h = self.halves_ok(vol, dtype)
-        wa, wb = self.w.detach()[:, :h], self.w.detach()[:, h:]
-        pa = self.cache.get(wa, dtype, ("fa", h, vol), lambda: hip.pack_conv_k3(wa, dtype, vol=vol))
-        pb = self.cache.get(wb, dtype, ("fb", h, vol), lambda: hip.pack_conv_k3(wb, dtype, vol=vol))
         y = _empty_like_vol(x, self.cout)
-        hip.conv3d_k3(x[..., :h], pa, self.b, y, h, self.cout)
         stats = torch.empty(x.shape[0], self.cout, 2, dtype=torch.float32, device=x.device)
-        hip.conv3d_k3_accumulate(x[..., h:], pb, y, h, self.cout, stats)
+        for i in range(self.cin // h):       # two parts, or 2 / 4 slices of 32 channels (inference, 24^3 level)
+            wi = self.w.detach()[:, i * h:(i + 1) * h]
+            pi = self.cache.get(wi, dtype, ("fp", i, h, vol), lambda wi=wi: hip.pack_conv_k3(wi, dtype, vol=vol))
+            xi = x[..., i * h:(i + 1) * h]
+            if i == 0:
+                hip.conv3d_k3(xi, pi, self.b, y, h, self.cout)
+            else:
+                hip.conv3d_k3_accumulate(xi, pi, y, h, self.cout, stats)
         return y, stats
 
     def split_ok(self, vol, dtype, ca, cb_) -> bool:

@@ -134,7 +134,10 @@ def test_conv3d_k3_channel_slices(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,k,s,p,sp", [(1, 32, 3, 1, 1, (16, 16, 16)), (1, 48, 2, 2, 0, (12, 12, 12)),
-                                                (4, 16, 3, 1, 1, (8, 8, 8)), (2, 48, 2, 2, 0, (10, 6, 14))])
+                                                (4, 16, 3, 1, 1, (8, 8, 8)), (2, 48, 2, 2, 0, (10, 6, 14)),
+                                                # 1x1x1 conv of a one-channel volume (UnetResBlock conv3 of Swin-UNETR's encoder1):
+                                                # bf16 runs on the stem kernels (centre tap only), ragged tiles
+                                                (1, 48, 1, 1, 0, (9, 14, 35)), (1, 32, 1, 1, 0, (16, 16, 16))])
 def test_conv3d_gather(dtype, cin, cout, k, s, p, sp):
     from medicalsemseg_amd import hip
     dev = _dev()
