@@ -334,9 +334,18 @@ class Conv3:
         hip.conv3d_k3_accumulate(xb, pb, y, 32, self.cout, stats)
         return y, stats
 
-    def bwd(self, x, dy, need_dx=True, dx_out=None, bias_grad_is_zero=False, next_norm=None):
+    def dgrad_accumulate_ok(self, dy) -> bool:
+        """can the input gradient be ADDED onto a tensor that already holds another gradient of the input (the accumulate
+        epilogue of the ping-pong kernels: 32 or 48 output channels of the forward conv, large grids)?"""
+        if dy.dtype != torch.bfloat16 or self.cout not in (32, 48) or dy.shape[0] > 4 or os.environ.get("MSSEG_NO_DGRAD_ACCUM"):
+            return False
+        vol = tuple(dy.shape[:4])
+        return hip.lib().msseg_conv3d_k3_kernel(*vol, self.cout, self.cin, hip.BF16) == (4 if self.cout == 48 else 3)
+
+    def bwd(self, x, dy, need_dx=True, dx_out=None, bias_grad_is_zero=False, next_norm=None, accumulate_dx=False):
         """next_norm = (InstNormAct, yraw, stats, act) of the layer whose activation is this conv's input: its
-        InstanceNorm-backward reductions are then fused into the input-gradient kernel; returns (dx, red)."""
+        InstanceNorm-backward reductions are then fused into the input-gradient kernel; returns (dx, red).
+        accumulate_dx (with dx_out, dgrad_accumulate_ok()): dx_out += the input gradient (one rounding of the sum)."""
         dtype = x.dtype
         if self.w.requires_grad:
             g, acc = _grad_buf(self.w)
@@ -358,6 +367,13 @@ class Conv3:
         if self._gather(dtype):
             raise NotImplementedError("input gradient of a few-channel stem conv is never needed on this path")
         vol = tuple(dy.shape[:4])
+        if accumulate_dx:
+            assert dx_out is not None and next_norm is None and self.dgrad_accumulate_ok(dy)
+            wp = self.cache.get(self.w, dtype, ("d", vol),
+                                lambda: hip.pack_conv_k3(self.w.detach(), dtype, dgrad=True, vol=vol))
+            unused = torch.empty(dy.shape[0], self.cin, 2, dtype=torch.float32, device=dy.device)   # the epilogue's statistics
+            hip.conv3d_k3_accumulate(dy, wp, dx_out, self.cout, self.cin, unused)
+            return dx_out
         if hip.conv3d_k3_small_ok(dy, self.cout, self.cin):
             # small grid: split-K partials, then ONE finish kernel = the plain sum, or the receiving unit's whole backward
             wp = self.cache.get(self.w, dtype, "ds", lambda: hip.pack_conv_k3(self.w.detach(), dtype, dgrad=True, cb=32))
@@ -704,6 +720,16 @@ class ResBlock:
         dy2, dres = self.n2.bwd(y2, s2, o, do, want_dres=True)
         da1, red1 = self.c2.bwd(a1, dy2, True, next_norm=(self.n1, y1, s1, a1))
         dy1 = self.n1.bwd(y1, s1, a1, da1, red=red1)
+        if need_dx and self.c1.dgrad_accumulate_ok(dy1):
+            # large grids (Swin-UNETR's 96^3 / 48^3 UnetResBlocks): the gradient of the shortcut first, then the first conv's
+            # input gradient is added onto it by that kernel's epilogue -- no separate add pass over the (up to 96-channel)
+            # input gradient (3 x 340 MB at 96^3, batch 2)
+            if self.c3 is not None:
+                dy3 = self.n3.bwd(y3, s3, r, dres)
+                dx3 = self.c3.bwd(x, dy3, True)
+            else:
+                dx3 = dres
+            return self.c1.bwd(x, dy1, True, dx_out=dx3, accumulate_dx=True)
         dx = self.c1.bwd(x, dy1, need_dx)
         if self.c3 is not None:
             dy3 = self.n3.bwd(y3, s3, r, dres)
