@@ -200,6 +200,11 @@ class _WgradSide:
 WGRAD_SIDE = _WgradSide()
 
 
+# set by a network's inference-only forward (nothing kept for a backward: models/unet.py _forward_cl(keep=False)) around its
+# layer calls: enables forms that only pay when no backward follows (Conv3.halves_ok: K-split of the 24^3-level convs)
+INFERENCE_FORWARD = False
+
+
 class _Applied:
     """what Conv3.bwd returns in place of the InstanceNorm-backward sums when its finish kernel already ran the receiving
     unit's whole backward (small-grid path): the tensor it returned IS that unit's dy"""
@@ -282,7 +287,7 @@ class Conv3:
         # inference only (sliding window, 8 windows per launch): the 64- / 128-input-channel convs of the 24^3 level as 2 / 4
         # launches of the 32-channel ping-pong kernel on channel slices of the input (the generic kernel runs them at 250 TFLOP/s:
         # chains of 32-channel stages on 4x4x8 tiles); in training that grid (batch 2) is too small for the ping-pong kernel
-        if (not torch.is_grad_enabled() and self.cin in (64, 128) and self.cout % 32 == 0 and not os.environ.get("MSSEG_NO_KSPLIT_INFER")
+        if (INFERENCE_FORWARD and self.cin in (64, 128) and self.cout % 32 == 0 and not os.environ.get("MSSEG_NO_KSPLIT_INFER")
                 and hip.lib().msseg_conv3d_k3_kernel(*vol, 32, self.cout, hip.BF16) == 3):
             return 32
         # 64 -> 2 x 32 on the 32-channel ping-pong kernel (BasicUNet's UpCat convs in TRAINING, where the concat buffer exists

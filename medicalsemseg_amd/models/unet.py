@@ -159,6 +159,15 @@ class UNet(nn.Module):
 def _forward_cl(net: "UNet", x, keep: bool):
     """x: channels-last [N, D, H, W, Cin] in the compute dtype -> (logits_cl [N, D, H, W, LOGIT_LD], saved, last, skips).
     keep=False (inference): nothing is retained, every intermediate is released as soon as its consumer is issued."""
+    prev = layers.INFERENCE_FORWARD
+    layers.INFERENCE_FORWARD = not keep
+    try:
+        return _forward_cl_body(net, x, keep)
+    finally:
+        layers.INFERENCE_FORWARD = prev
+
+
+def _forward_cl_body(net: "UNet", x, keep: bool):
     T = net.compute_dtype
     N, D, H, W, _ = x.shape
     dev = x.device
