@@ -18,7 +18,7 @@ for r in rows:
     k = r['Kernel_Name'][:60]
     agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
-    if 'igemm' in k or 'instnorm' in k or 'stats' in k or 'k3pp' in k or 'k3wg' in k:
+    if 'igemm' in k or 'instnorm' in k or 'stats' in k or 'k3pp' in k or 'k3wg' in k or 'k3c48' in k:
         print(k, {c: sum(v)/len(v) for c, v in d.items()}, 'launches', len(list(d.values())[0]))
 print(open('gpurun_out/$tag/run.log').read()[-300:])
 PY
