@@ -507,6 +507,23 @@ int msseg_sw_blend_batch(const void* win, long long ldw, int dtype, const float*
                          int RD, int RH, int RW, msseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Layout passes of the vendored MONAI Swin-UNETR encoder (csrc/layout.hip; /root/reference/models/segmentors/
+ * swin_unetr_official.py:244-270,699-712), channels-last volumes, 16-byte channel chunks (C % 8 == 0 bf16, % 4 fp32).
+ * msseg_box_copy: dst[n, d, h, w, :C] = src[n, d, h, w, :C] inside the common box, zero elsewhere in dst -- F.pad with zeros at
+ *   the high end when dst is larger, the crop x[:, :d, :h, :w] when it is smaller (each is the other's adjoint).
+ * msseg_merge_gather_fwd: out[n, i, j, k, s*C + c] = x[n, 2i + a_s, 2j + b_s, 2k + c_s, c] (zero beyond the grid) for eight
+ *   sub-grids; `subs` holds 3 bits per slot s at bits 3s..3s+2 (bit 0: offset along D, bit 1: H, bit 2: W); duplicates allowed
+ *   (PatchMerging's x5 == x2, x6 == x3).  out: [N, ceil(D/2), ceil(H/2), ceil(W/2), 8C].  _bwd: the adjoint (per fine voxel the
+ *   sum, in slot order, of the slots whose offset equals the voxel's parity; deterministic).
+ * ------------------------------------------------------------------------------------------- */
+int msseg_box_copy(const void* src, long long lds, int SD, int SH, int SW, void* dst, long long ldd, int DD, int DH, int DW,
+                   int N, int C, int dtype, msseg_stream_t stream);
+int msseg_merge_gather_fwd(const void* x, long long ldx, int D, int H, int W, void* out, long long ldo, int N, int C,
+                           unsigned subs, int dtype, msseg_stream_t stream);
+int msseg_merge_gather_bwd(const void* dy, long long lddy, void* dx, long long lddx, int N, int D, int H, int W, int C,
+                           unsigned subs, int dtype, msseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Post-inference (the step right after the path).
  * argmax_u8: out[v] = first arg max over c of logits[c][v] (NCDHW fp32, one sample) -- engine/test.py:140-141
  *            (softmax is monotonic, so it is skipped).

@@ -114,6 +114,9 @@ SIGNATURES = {
     "msseg_sw_blend": ([_vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_sw_normalize": ([_vp, _vp, _i, _ll, _vp], _i),
     "msseg_sw_gather": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "msseg_box_copy": ([_vp, _ll, _i, _i, _i, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "msseg_merge_gather_fwd": ([_vp, _ll, _i, _i, _i, _vp, _ll, _i, _i, C.c_uint, _i, _vp], _i),
+    "msseg_merge_gather_bwd": ([_vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, C.c_uint, _i, _vp], _i),
     "msseg_argmax_u8": ([_vp, _i, _ll, _vp, _vp], _i),
     "msseg_resample_nearest_u8": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _vp], _i),
     "msseg_majority_vote_u8": ([_vp, _i, _ll, _i, _vp, _vp], _i),
@@ -1257,6 +1260,44 @@ def conv3d_k3s2(x, wp, bias, y, cin, cout):
     _ck(lib().msseg_conv3d_k3s2_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cin, cout, dt(x),
                                     _stream()), "conv3d_k3s2_fwd")
     return y
+
+
+def box_copy(src, dst):
+    """dst[n, d, h, w, :] = src[n, d, h, w, :] inside the common box, zero elsewhere in dst (channels-last [N, D, H, W, C]): zero
+    padding at the high end of the spatial axes, or the crop back -- each is the other's adjoint (csrc/layout.hip)"""
+    _need_gpu(src, dst)
+    N, SD, SH, SW, Cc = src.shape
+    _, DD, DH, DW, Cd = dst.shape
+    if Cc != Cd or dst.shape[0] != N or src.dtype != dst.dtype:
+        raise ValueError("box_copy: batch, channel count and dtype must agree")
+    _ck(lib().msseg_box_copy(_p(src), ld(src), SD, SH, SW, _p(dst), ld(dst), DD, DH, DW, N, Cc, dt(src), _stream()), "box_copy")
+    return dst
+
+
+def merge_subs(offsets) -> int:
+    """eight (a, b, c) sub-grid offsets along (D, H, W) -> the packed `subs` word of merge_gather"""
+    assert len(offsets) == 8
+    word = 0
+    for s, (a, b, c) in enumerate(offsets):
+        word |= (a | (b << 1) | (c << 2)) << (3 * s)
+    return word
+
+
+def merge_gather(x, out, subs):
+    """out[n, i, j, k, s*C + c] = x[n, 2i + a_s, 2j + b_s, 2k + c_s, c] (zero beyond the grid): PatchMerging's eight strided
+    slices + concat in one pass"""
+    _need_gpu(x, out)
+    N, D, H, W, Cc = x.shape
+    _ck(lib().msseg_merge_gather_fwd(_p(x), ld(x), D, H, W, _p(out), ld(out), N, Cc, subs, dt(x), _stream()), "merge_gather_fwd")
+    return out
+
+
+def merge_gather_bwd(dy, dx, subs):
+    """adjoint of merge_gather: dx [N, D, H, W, C] from dy [N, ceil(D/2), ceil(H/2), ceil(W/2), 8C]"""
+    _need_gpu(dy, dx)
+    N, D, H, W, Cc = dx.shape
+    _ck(lib().msseg_merge_gather_bwd(_p(dy), ld(dy), _p(dx), ld(dx), N, D, H, W, Cc, subs, dt(dx), _stream()), "merge_gather_bwd")
+    return dx
 
 
 def zero_stuff2(dy, out):

@@ -18,7 +18,6 @@ from typing import Sequence
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import hip, ops
 from ..layers import Conv1
@@ -72,11 +71,11 @@ class _Block(nn.Module):
         xn = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         pad = (ws - d % ws) % ws
         if pad:                                       # zero tokens AFTER the norm (their qkv is the bias), cropped below
-            xn = F.pad(xn, (0, 0, 0, pad, 0, pad, 0, pad))
+            xn = ops.box_resize(xn, (d + pad, h + pad, w + pad))
         qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias)
         y = ops.WindowAttnFn.apply(qkv, a.qkv.bias, a.relative_position_bias_table, self.heads, ws, shift, a.ws)
         if pad:
-            y = y[:, :d, :h, :w, :].contiguous()
+            y = ops.box_resize(y, (d, h, w))
         y = ops.linear(y, a.proj.weight, a.proj.bias)   # per-token: commutes with the crop
         x = ops.add(x, y)
         y = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
@@ -92,11 +91,10 @@ class _PatchMerging(nn.Module):
 
     def forward(self, x):
         B, d, h, w, C = x.shape
-        if (h % 2 == 1) or (w % 2 == 1) or (d % 2 == 1):
-            x = F.pad(x, (0, 0, 0, d % 2, 0, w % 2, 0, h % 2))
-        # sub-grids in the reference's order, including its duplicates (x5 == x2, x6 == x3)
+        # sub-grids in the reference's order, including its duplicates (x5 == x2, x6 == x3); an odd grid is zero-padded by the
+        # gather itself (one kernel for F.pad + eight strided slices + torch.cat, one for their backward)
         sub = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 0), (0, 0, 1), (1, 1, 1)]
-        x = torch.cat([x[:, a::2, b::2, c::2, :] for a, b, c in sub], -1)
+        x = ops.merge_gather(x, sub)
         x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return ops.linear(x, self.reduction.weight, None)
 

@@ -194,6 +194,51 @@ class AddFn(torch.autograd.Function):
         return dy, hip.axpy_rows(None, dy, ctx.scale, torch.empty_like(dy)), None
 
 
+class BoxCopyFn(torch.autograd.Function):
+    """zero padding at the high end of the spatial axes of a token volume [B, D, H, W, C] (F.pad(x, (0, 0, 0, pw, 0, ph, 0, pd))) or
+    the crop x[:, :d, :h, :w] back, as one pass each way (csrc/layout.hip; the two are each other's adjoint)"""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        x = _c(x)
+        ctx.src_size = tuple(x.shape[1:4])
+        return hip.box_copy(x, torch.empty((x.shape[0],) + tuple(size) + (x.shape[4],), dtype=x.dtype, device=x.device))
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty((dy.shape[0],) + ctx.src_size + (dy.shape[4],), dtype=dy.dtype, device=dy.device)
+        return hip.box_copy(dy, dx), None
+
+
+def box_resize(x, size):
+    """x zero-padded (at the high end) or cropped to the spatial size `size`"""
+    return BoxCopyFn.apply(x, tuple(int(v) for v in size))
+
+
+class MergeGatherFn(torch.autograd.Function):
+    """torch.cat([x[:, a::2, b::2, c::2, :] for (a, b, c) in offsets], -1) of a token volume, odd sizes zero-padded first: the
+    sub-grid gather of MONAI's PatchMerging (/root/reference/models/segmentors/swin_unetr_official.py:699-708) in one pass,
+    its adjoint in one pass (duplicated sub-grids are summed in slot order)"""
+
+    @staticmethod
+    def forward(ctx, x, offsets):
+        x = _c(x)
+        B, D, H, W, C = x.shape
+        ctx.subs, ctx.shape = hip.merge_subs(offsets), tuple(x.shape)
+        out = torch.empty(B, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, 8 * C, dtype=x.dtype, device=x.device)
+        return hip.merge_gather(x, out, ctx.subs)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        return hip.merge_gather_bwd(dy, torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device), ctx.subs), None
+
+
+def merge_gather(x, offsets):
+    return MergeGatherFn.apply(x, tuple(tuple(o) for o in offsets))
+
+
 class WindowAttnFn(torch.autograd.Function):
     """shifted-window attention core on a token volume: qkv [B,S,H,W,3C] -> [B,S,H,W,C]"""
 

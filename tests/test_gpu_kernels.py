@@ -1027,6 +1027,43 @@ def test_deconv_bwd_small_unit(cin, cout, sp, N):
         assert float((a_ - bb).abs().max()) / (float(bb.abs().max()) + 1e-6) < 2e-3, nm
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sp,C", [((6, 6, 6), 24), ((5, 7, 9), 16), ((13, 13, 13), 48)])
+def test_layout_kernels_pad_crop_merge_gather(dtype, sp, C):
+    """csrc/layout.hip against the torch ops the vendored MONAI encoder uses (F.pad / crop of the window partition, the eight
+    strided slices + concat of PatchMerging with its duplicated sub-grids, odd sizes) -- forward and adjoint, bit for bit (the
+    adjoint of the duplicated sub-grids adds two values: one rounding, as torch's)"""
+    from medicalsemseg_amd import ops
+    dev = _dev()
+    N = 2
+    x = (torch.randn(N, *sp, C, generator=torch.Generator().manual_seed(1))).to(dev, dtype).requires_grad_(True)
+    big = tuple(v + p for v, p in zip(sp, (1, 2, 3)))
+    # pad, then crop back
+    y = ops.box_resize(x, big)
+    ref = F.pad(x.detach(), (0, 0, 0, 3, 0, 2, 0, 1))
+    assert torch.equal(y, ref)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).to(dev, dtype)
+    y.backward(g)
+    assert torch.equal(x.grad, g[:, :sp[0], :sp[1], :sp[2]])
+    x.grad = None
+    z = ops.box_resize(y.detach().requires_grad_(True), sp)
+    assert torch.equal(z, x.detach())
+    # PatchMerging gather
+    sub = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 0), (0, 0, 1), (1, 1, 1)]
+    m = ops.merge_gather(x, sub)
+    xr = x.detach().clone().requires_grad_(True)
+    xp = F.pad(xr, (0, 0, 0, sp[2] % 2, 0, sp[1] % 2, 0, sp[0] % 2))
+    mref = torch.cat([xp[:, a::2, b::2, c::2, :] for a, b, c in sub], -1)
+    assert torch.equal(m, mref.detach())
+    gm = torch.randn(m.shape, generator=torch.Generator().manual_seed(3)).to(dev, dtype)
+    m.backward(gm)
+    mref.backward(gm)
+    if dtype == torch.float32:
+        assert torch.equal(x.grad, xr.grad)
+    else:   # torch adds the duplicated sub-grids' gradients in bf16 (two roundings where three terms meet: none here, two terms)
+        assert float((x.grad.float() - xr.grad.float()).abs().max()) <= 2 ** -7 * float(xr.grad.float().abs().max())
+
+
 def test_postproc_kernels_bit_exact(golden_dir):
     """argmax -> uint8, nearest resample (scipy order-0 zoom semantics) and the fold majority vote: bit-exact against the
     numpy oracle, the reference's resample_3d fixture (tests/golden/resample.npz) and ragged sizes"""
