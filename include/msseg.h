@@ -423,6 +423,12 @@ int msseg_layernorm_fwd(const void* x, long long ldx, const float* gamma, const 
 int msseg_layernorm_bwd(const void* x, long long ldx, const float* gamma, const float* mean, const float* rstd,
                         const void* dy, long long lddy, void* dx, long long lddx, long long rows, int C, int dtype,
                         msseg_stream_t stream);
+/* ... + add: dx = T(layernorm backward) + add, the sum autograd forms when the normalised tensor also feeds a residual branch
+ * (x -> LayerNorm and x -> x + f(LayerNorm(x)) in every Swin block, /root/reference/models/backbones/swin_nnformer.py:243-262):
+ * one pass instead of the backward + a separate add.  Vector kernel only (C a multiple of the 16-byte chunk, <= 4096). */
+int msseg_layernorm_bwd_add(const void* x, long long ldx, const float* gamma, const float* mean, const float* rstd,
+                            const void* dy, long long lddy, const void* add, long long ldadd, void* dx, long long lddx,
+                            long long rows, int C, int dtype, msseg_stream_t stream);
 /* parameter gradients dgamma[c] (+)= sum_rows dy*xhat, dbeta[c] (+)= sum_rows dy (deterministic two-stage reduction) */
 int msseg_layernorm_param_grad(const void* x, long long ldx, const float* mean, const float* rstd, const void* dy,
                                long long lddy, float* dgamma, float* dbeta, int accumulate, long long rows, int C,

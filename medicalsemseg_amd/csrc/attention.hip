@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 struct LnVecParams {
     const void* x; long long ldx; const float* g; const float* b; void* y; long long ldy;
     float* mean; float* rstd; const void* dy; long long lddy; long long rows; int C, lpr, nch; float eps;
+    const void* add; long long ldadd;   // backward: dx = T(layernorm backward) + add (the gradient of a residual branch that left x)
 };
 
 template <typename T> MSSEG_DEVFN void ln_load(const T* p, float (&v)[DT<T>::EPC]) {
@@ -412,6 +413,12 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const LnVecParams p)
                     float o[EPC];
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) o[e] = rs * (dv[k][e] * gv[k][e] - a - (xv[k][e] - mu) * rs * b);
+                    if (p.add) {   // the sum autograd forms for a tensor with two consumers: both terms rounded to T, then added
+                        float r2[EPC];
+                        ln_load<T>((const T*)p.add + r * p.ldadd + ch * EPC, r2);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) o[e] = (float)(T)o[e] + r2[e];
+                    }
                     ln_store<T>((T*)p.y + r * p.ldy + ch * EPC, o);
                 }
             }
@@ -650,6 +657,23 @@ int msseg_layernorm_bwd(const void* x, long long ldx, const float* gamma, const 
                            ldx, gamma, mean, rstd, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, dgamma, dbeta, rows, C);
     else MSSEG_FAIL(MSSEG_EINVAL, "layernorm_bwd: bad dtype");
     MSSEG_CHECK_LAUNCH("layernorm_bwd");
+    return MSSEG_OK;
+}
+
+int msseg_layernorm_bwd_add(const void* x, long long ldx, const float* gamma, const float* mean, const float* rstd,
+                            const void* dy, long long lddy, const void* add, long long ldadd, void* dx, long long lddx,
+                            long long rows, int C, int dtype, msseg_stream_t stream) {
+    if (!x || !mean || !rstd || !dy || !dx || !add || rows < 1 || C < 1) MSSEG_FAIL(MSSEG_EINVAL, "layernorm_bwd_add: bad args");
+    if (dtype != MSSEG_F32 && dtype != MSSEG_BF16) MSSEG_FAIL(MSSEG_EINVAL, "layernorm_bwd_add: bad dtype");
+    const size_t esz = dtype == MSSEG_F32 ? 4 : 2;
+    if (((uintptr_t)add & 15) || (ldadd * esz) % 16) MSSEG_FAIL(MSSEG_EINVAL, "layernorm_bwd_add: `add` must have 16-byte aligned rows");
+    LnVecParams v{};
+    v.x = x; v.ldx = ldx; v.g = gamma; v.y = dx; v.ldy = lddx; v.mean = (float*)mean; v.rstd = (float*)rstd;
+    v.dy = dy; v.lddy = lddy; v.rows = rows; v.C = C; v.add = add; v.ldadd = ldadd;
+    const bool done = dtype == MSSEG_F32 ? launch_ln_vec<float, true>(v, (hipStream_t)stream)
+                                         : launch_ln_vec<bf16_t, true>(v, (hipStream_t)stream);
+    if (!done) MSSEG_FAIL(MSSEG_EINVAL, "layernorm_bwd_add: rows of %d channels do not take the vector kernel (16-byte chunks, <= 4096 channels)", C);
+    MSSEG_CHECK_LAUNCH("layernorm_bwd_add");
     return MSSEG_OK;
 }
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "msseg_window_attention_bwd_workspace_bytes": ([_i, _i, _i, _i, _i, _i, _i, _i, _i], _sz),
     "msseg_layernorm_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _ll, _i, _f, _i, _vp], _i),
     "msseg_layernorm_bwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _vp], _i),
+    "msseg_layernorm_bwd_add": ([_vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _ll, _ll, _i, _i, _vp], _i),
     "msseg_layernorm_param_grad": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _i, _ll, _i, _vp, _sz, _i, _vp], _i),
     "msseg_gelu_fwd": ([_vp, _vp, _ll, _i, _vp], _i),
     "msseg_gelu_bwd": ([_vp, _vp, _vp, _ll, _i, _vp], _i),
@@ -1350,12 +1351,23 @@ def layernorm_fwd(x, gamma, beta, y, eps=1e-5, save=True):
     return mean, rstd
 
 
-def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma=None, dbeta=None, accumulate=False):
+def layernorm_bwd_add_ok(x) -> bool:
+    """does layernorm_bwd(..., add=) take rows shaped like x's (the vector kernel: 16-byte chunks, at most 4096 channels)?"""
+    epc = 16 // x.element_size()
+    return x.shape[-1] % epc == 0 and x.shape[-1] <= 512 * epc and x.data_ptr() % 16 == 0
+
+
+def layernorm_bwd(x, gamma, mean, rstd, dy, dx, dgamma=None, dbeta=None, accumulate=False, add=None):
+    """add (optional, shaped like x): dx = layernorm backward + add in the same pass (layernorm_bwd_add_ok(x))"""
     _need_gpu(x, dy, dx)
     Cc = x.shape[-1]
     rows = x.numel() // Cc
-    _ck(lib().msseg_layernorm_bwd(_p(x), ld(x), _p(gamma), _p(mean), _p(rstd), _p(dy), ld(dy), _p(dx), ld(dx),
-                                  rows, Cc, dt(x), _stream()), "layernorm_bwd")
+    if add is not None:
+        _ck(lib().msseg_layernorm_bwd_add(_p(x), ld(x), _p(gamma), _p(mean), _p(rstd), _p(dy), ld(dy), _p(add), ld(add), _p(dx),
+                                          ld(dx), rows, Cc, dt(x), _stream()), "layernorm_bwd_add")
+    else:
+        _ck(lib().msseg_layernorm_bwd(_p(x), ld(x), _p(gamma), _p(mean), _p(rstd), _p(dy), ld(dy), _p(dx), ld(dx),
+                                      rows, Cc, dt(x), _stream()), "layernorm_bwd")
     if dgamma is not None:
         sc = scratch(x.device)
         _ck(lib().msseg_layernorm_param_grad(_p(x), ld(x), _p(mean), _p(rstd), _p(dy), ld(dy), _p(dgamma), _p(dbeta),

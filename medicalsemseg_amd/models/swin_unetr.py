@@ -250,12 +250,12 @@ class _Block(nn.Module):
 
     def forward(self, x):
         a = self.attn
-        xn = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x, xn = ops.layer_norm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)   # x: the residual, through the node
         qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias)
         y = ops.WindowAttnFn.apply(qkv, a.qkv.bias, a.relative_position_bias_table, self.heads, self.ws, self.shift)
         y = ops.linear(y, a.proj.weight, a.proj.bias)
         x = ops.add(x, y, self._dp_scale(x))
-        y = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x, y = ops.layer_norm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         if isinstance(self.mlp, (_DepthMlp, _InceptionMlp)):
             y = self.mlp.run(y)
         else:

@@ -68,7 +68,7 @@ class _Block(nn.Module):
         if d <= ws:                                   # get_window_size: clamp the window, no shift
             ws, shift = d, 0
         a = self.attn
-        xn = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x, xn = ops.layer_norm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)   # x: the residual, through the node
         pad = (ws - d % ws) % ws
         if pad:                                       # zero tokens AFTER the norm (their qkv is the bias), cropped below
             xn = ops.box_resize(xn, (d + pad, h + pad, w + pad))
@@ -78,7 +78,7 @@ class _Block(nn.Module):
             y = ops.box_resize(y, (d, h, w))
         y = ops.linear(y, a.proj.weight, a.proj.bias)   # per-token: commutes with the crop
         x = ops.add(x, y)
-        y = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x, y = ops.layer_norm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         y = ops.mlp(y, self.mlp.linear1.weight, self.mlp.linear1.bias, self.mlp.linear2.weight, self.mlp.linear2.bias)
         return ops.add(x, y)
 

@@ -158,6 +158,49 @@ class LayerNormFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class LayerNormResFn(torch.autograd.Function):
+    """(x, LayerNorm(x)) as ONE autograd node: a Swin block uses x twice -- normalised into the attention / MLP branch and as
+    the residual (swin_nnformer.py:243-262) -- and autograd sums the two gradients of a tensor with two consumers with a
+    separate add kernel.  Here the node hands x through as its first output, so x has one consumer, and the backward adds the
+    residual's gradient inside the LayerNorm backward kernel (msseg_layernorm_bwd_add): same rounding, one pass less."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        y = torch.empty_like(x)
+        mean, rstd = hip.layernorm_fwd(x, gamma, beta, y, eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta = gamma, beta
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.gamma, ctx.beta
+        if dy is None:
+            return dres, None, None, None
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dg = db = None
+        acc = False
+        if ctx.needs_input_grad[1]:
+            dg, acc = _gbuf(gamma)
+            db, _ = _gbuf(beta)
+        if dres is not None and hip.layernorm_bwd_add_ok(x):
+            hip.layernorm_bwd(x, gamma, mean, rstd, dy, dx, dg, db, acc, add=_c(dres))
+        else:
+            hip.layernorm_bwd(x, gamma, mean, rstd, dy, dx, dg, db, acc)
+            if dres is not None:
+                dx = dx + dres
+        return dx, None, None, None
+
+
+def layer_norm_res(x, gamma, beta, eps=1e-5):
+    """(x, LayerNorm(x)); take the residual from the first result (see LayerNormResFn)"""
+    return LayerNormResFn.apply(x, gamma, beta, eps)
+
+
 class GeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

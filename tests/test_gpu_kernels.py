@@ -1064,6 +1064,32 @@ def test_layout_kernels_pad_crop_merge_gather(dtype, sp, C):
         assert float((x.grad.float() - xr.grad.float()).abs().max()) <= 2 ** -7 * float(xr.grad.float().abs().max())
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,rows", [(48, 1000), (384, 77), (3072, 9)])
+def test_layer_norm_res_one_node_equals_two_consumers(dtype, C, rows):
+    """ops.layer_norm_res (x handed through the LayerNorm node, the residual's gradient added inside the LayerNorm backward kernel)
+    == x feeding ops.layer_norm and the residual separately (autograd's own add of the two gradients), bit for bit"""
+    from medicalsemseg_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x0 = (torch.randn(2, rows, 1, 1, C, generator=g) * 2 + 0.5).to(dev, dtype)
+    w = torch.nn.Parameter((torch.randn(C, generator=g) * 0.2 + 1).to(dev))
+    b = torch.nn.Parameter((torch.randn(C, generator=g) * 0.2).to(dev))
+    gy, gr = (torch.randn(x0.shape, generator=g).to(dev, dtype) for _ in range(2))
+    res = []
+    for fused in (True, False):
+        x = x0.clone().requires_grad_(True)
+        w.grad = b.grad = None
+        if fused:
+            xr, y = ops.layer_norm_res(x, w, b, 1e-5)
+        else:
+            xr, y = x, ops.layer_norm(x, w, b, 1e-5)
+        torch.autograd.backward([y, xr * 1.0 if not fused else xr], [gy, gr])
+        res.append((y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone()))
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
+
+
 def test_postproc_kernels_bit_exact(golden_dir):
     """argmax -> uint8, nearest resample (scipy order-0 zoom semantics) and the fold majority vote: bit-exact against the
     numpy oracle, the reference's resample_3d fixture (tests/golden/resample.npz) and ragged sizes"""
