@@ -122,13 +122,20 @@ int msseg_conv3d_k3s2_fwd(const void* x, long long ldx, const void* wp, const fl
                           int N, int ID, int IH, int IW, int Cin, int Cout, int dtype, msseg_stream_t stream);
 int msseg_zero_stuff2(const void* dy, long long lddy, void* out, long long ldo, int N, int OD, int OH, int OW, int ID,
                       int IH, int IW, int C, int dtype, msseg_stream_t stream);
-/* Conv3d k=3 s=1 p=1 with ONE input channel (BasicUNet conv_0.conv_0, the stem): dedicated kernel, bf16, Cout % 32 == 0;
+/* Conv3d k=3 s=1 p=1 with ONE input channel (BasicUNet conv_0.conv_0, the stem): dedicated kernel, bf16, Cout % 32 == 0 or
+ * % 48 == 0 (Swin-UNETR's 1 -> 48 first conv); y == NULL with stats != NULL: statistics only, nothing is stored;
  * wp = the msseg_pack_weights image used by msseg_conv3d_gather_fwd (K = 27); optional fused statistics as
  * msseg_conv3d_k3_fwd.  msseg_conv3d_gather_fwd / _wgrad route eligible problems here by themselves; this entry
  * point adds the statistics.  Returns MSSEG_EINVAL for problems the stem kernel does not cover. */
 int msseg_conv3d_stem_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                           int N, int D, int H, int W, int Cout, float* stats, void* scratch, size_t scratch_bytes,
                           int dtype, msseg_stream_t stream);
+/* Inference form of the stem unit: y = lrelu(instance_norm(conv(x) + bias) * gamma + beta) with the statistics stats[N][Cout][2]
+ * of a statistics-only msseg_conv3d_stem_fwd call in front -- the one-channel conv is cheap enough to run twice, and the raw
+ * output's write and the normalisation pass over it disappear (sliding-window inference of BasicUNet at 96^3 windows). */
+int msseg_conv3d_stem_norm_fwd(const void* x, long long ldx, const void* wp, const float* bias, const float* stats,
+                               const float* gamma, const float* beta, float eps, float slope, void* y, long long ldy, int N,
+                               int D, int H, int W, int Cout, int dtype, msseg_stream_t stream);
 /* Conv3d k=1 (UnetResBlock.conv3, UnetOutBlock models/segmentors/swin_unetr.py:130, BasicUNet final_conv). */
 int msseg_conv3d_k1_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                         long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);

@@ -989,6 +989,19 @@ int msseg_conv3d_k3s2_fwd(const void* x, long long ldx, const void* wp, const fl
                               : launch_nt<bf16_t, 27, SRC_DIRECT, EPI_STORE, 2, 4, 8, 4, 2>(p, (hipStream_t)stream);
 }
 
+int msseg_conv3d_stem_norm_fwd(const void* x, long long ldx, const void* wp, const float* bias, const float* stats,
+                               const float* gamma, const float* beta, float eps, float slope, void* y, long long ldy, int N,
+                               int D, int H, int W, int Cout, int dtype, msseg_stream_t stream) {
+    if (!x || !wp || !y || !stats || N < 1 || D < 1 || H < 1 || W < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem_norm: bad args");
+    if (!msseg_stem_eligible(dtype, 1, Cout, 3, 1, 1, ldx, ldy, y))
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem_norm: bf16, Cout a multiple of 32 or 48 (<= 256), 8-byte aligned output rows only");
+    StemParams sp{};
+    sp.x = x; sp.ldx = ldx; sp.wp = wp; sp.bias = bias; sp.y = y; sp.ldy = ldy;
+    sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.M = Cout;
+    sp.nstats = stats; sp.gamma = gamma; sp.beta = beta; sp.eps = eps; sp.slope = slope;
+    return msseg_stem_fwd_launch(sp, (hipStream_t)stream);
+}
+
 int msseg_conv3d_k1_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                         long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream) {
     const int esz = dtype == MSSEG_F32 ? 4 : 2;
@@ -1035,9 +1048,9 @@ int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const 
 int msseg_conv3d_stem_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                           int N, int D, int H, int W, int Cout, float* stats, void* scratch, size_t scratch_bytes,
                           int dtype, msseg_stream_t stream) {
-    if (!x || !wp || !y || N < 1 || D < 1 || H < 1 || W < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem: bad args");
-    if (!msseg_stem_eligible(dtype, 1, Cout, 3, 1, 1, ldx, ldy, y))
-        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem: bf16, Cout %% 32 == 0 (<= 256), 8-byte aligned output rows only");
+    if (!x || !wp || (!y && !stats) || N < 1 || D < 1 || H < 1 || W < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem: bad args");
+    if (!msseg_stem_eligible(dtype, 1, Cout, 3, 1, 1, ldx, y ? ldy : 4, y))   // y == NULL: statistics only
+        MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem: bf16, Cout a multiple of 32 or 48 (<= 256), 8-byte aligned output rows only");
     StemParams sp{};
     sp.x = x; sp.ldx = ldx; sp.wp = wp; sp.bias = bias; sp.y = y; sp.ldy = ldy;
     sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.M = Cout;

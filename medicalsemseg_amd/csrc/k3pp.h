@@ -66,6 +66,9 @@ struct StemParams {
     int N, D, H, W, M;
     float* stats; float* stats_ws;    // optional fused statistics (partial rows -> msseg_k3_stats_finalize)
     int taps;                         // 27 (or 0): conv k3 p1; 1: the 1x1x1 conv of a one-channel volume (image with K = 1)
+    // y == nullptr (with stats): statistics only, nothing is stored.  nstats != nullptr: y = lrelu(instance_norm(conv) * gamma +
+    // beta) with the statistics nstats[N][M][2] of a previous statistics-only launch (inference: the raw output never exists)
+    const float* nstats; const float* gamma; const float* beta; float eps, slope;
 };
 struct StemWgParams {
     const void* x; long long ldx;

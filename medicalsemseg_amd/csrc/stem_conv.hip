@@ -60,7 +60,10 @@ struct Sched {
 constexpr int F_THREADS = 512;
 // JT = 16-wide cout tiles per cout block: 2 (32-wide blocks, BasicUNet's 1 -> 32 stem) or 3 (48-wide: the 1 -> 48 first conv of
 // Swin-UNETR's encoder1 UnetResBlock, /root/reference/models/segmentors/swin_unetr.py:73-81)
-template <int STATS, int JT>
+// NORM: the output is normalised with given statistics and activated before it is stored (no raw output, no statistics) -- with
+// a statistics-only launch in front (y == nullptr) this is conv + InstanceNorm + LeakyReLU of an inference forward without the
+// raw tensor's write and the normalisation pass's read + write: the one-channel conv is cheap enough to run twice
+template <int STATS, int JT, int NORM = 0>
 __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p) {
     constexpr int CBW = JT * 16;
     constexpr int F_STAT_FLOATS = 8 * MSSEG_STATS_NMAX * CBW * 2;
@@ -97,6 +100,26 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
     if (STATS) {
         for (int i = tid; i < F_STAT_FLOATS; i += F_THREADS) ldsS[i] = 0.f;
     }
+    float nsc[NORM ? JT : 1][4], nsh[NORM ? JT : 1][4];
+    int n_n = -1;
+    auto load_norm = [&](int n) {   // scale / shift of sample n: instnorm_kernel's arithmetic (elementwise.hip mean_rstd)
+        if constexpr (NORM != 0) {
+            const float inv = 1.0f / (float)((long long)p.D * p.H * p.W);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = coutblk * CBW + jt * 16 + q * 4 + e;
+                    const float su = p.nstats[((long long)n * p.M + c) * 2 + 0], su2 = p.nstats[((long long)n * p.M + c) * 2 + 1];
+                    const float mean = su * inv;
+                    float var = su2 * inv - mean * mean;
+                    var = var > 0.f ? var : 0.f;
+                    const float rstd = rsqrtf(var + p.eps);
+                    nsc[jt][e] = rstd * (p.gamma ? p.gamma[c] : 1.f);
+                    nsh[jt][e] = (p.beta ? p.beta[c] : 0.f) - mean * nsc[jt][e];
+                }
+        }
+    };
     float s1[JT][4], s2[JT][4];
     int s_n = -1;
 #pragma unroll
@@ -158,6 +181,9 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
         if constexpr (STATS != 0) {
             if (tc.n != s_n) { flush_stats(); s_n = tc.n; }
         }
+        if constexpr (NORM != 0) {
+            if (tc.n != n_n) { load_norm(tc.n); n_n = tc.n; }
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int hrow = h2 + m;
@@ -180,7 +206,17 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
                 mma_chunk<bf16_t>(acc, wf[jt], xf);
                 const f32x4_t o = acc + bv[jt];
                 const bf16x4_t ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
-                if (ok) *(bf16x4_t*)(yg + vox * p.ldy + coutblk * CBW + jt * 16 + q * 4) = ob;
+                if constexpr (NORM != 0) {   // from the value as the unfused chain stores it (bf16), in that chain's arithmetic
+                    bf16x4_t oa;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z = (float)ob[e] * nsc[jt][e] + nsh[jt][e];
+                        oa[e] = (bf16_t)(z > 0.f ? z : z * p.slope);
+                    }
+                    if (ok) *(bf16x4_t*)(yg + vox * p.ldy + coutblk * CBW + jt * 16 + q * 4) = oa;
+                } else {
+                    if (ok && yg != nullptr) *(bf16x4_t*)(yg + vox * p.ldy + coutblk * CBW + jt * 16 + q * 4) = ob;
+                }
                 if constexpr (STATS != 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -359,11 +395,15 @@ int msseg_stem_fwd_launch(const StemParams& p, hipStream_t stream) {
     gx &= ~7;
     if (gx < 8) gx = 8;
     if (gx > tiles) gx = tiles;
+    if (p.nstats != nullptr && p.stats != nullptr) MSSEG_FAIL(MSSEG_EINVAL, "stem_fwd: the normalised form emits no statistics");
+    if (p.y == nullptr && p.stats == nullptr) MSSEG_FAIL(MSSEG_EINVAL, "stem_fwd: nothing to produce");
     if (cbw == 32) {
-        if (p.stats) hipLaunchKernelGGL((stem_fwd_kernel<1, 2>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
+        if (p.nstats) hipLaunchKernelGGL((stem_fwd_kernel<0, 2, 1>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
+        else if (p.stats) hipLaunchKernelGGL((stem_fwd_kernel<1, 2>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
         else hipLaunchKernelGGL((stem_fwd_kernel<0, 2>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
     } else {
-        if (p.stats) hipLaunchKernelGGL((stem_fwd_kernel<1, 3>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
+        if (p.nstats) hipLaunchKernelGGL((stem_fwd_kernel<0, 3, 1>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
+        else if (p.stats) hipLaunchKernelGGL((stem_fwd_kernel<1, 3>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
         else hipLaunchKernelGGL((stem_fwd_kernel<0, 3>), dim3(gx, ncb), dim3(F_THREADS), 0, stream, p);
     }
     MSSEG_CHECK_LAUNCH("stem_fwd");

@@ -76,6 +76,7 @@ SIGNATURES = {
     "msseg_linear_gelu_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_linear_gelu_bwd": ([_vp, _ll, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_stem_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
+    "msseg_conv3d_stem_norm_fwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_conv3d_k1_head_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _ll, _i, _i, _vp, _ll, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                           _vp, _i, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_k1_head_norm_fwd": ([_vp, _ll, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _ll, _i, _ll, _i, _i, _i, _vp], _i),
@@ -721,12 +722,23 @@ def conv3d_gather(x, wp, bias, y, cin, cout, k, s, p):
     return y
 
 
+def conv3d_stem_norm(x, wp, bias, stats, gamma, beta, eps, slope, y, cout):
+    """y = lrelu(instance_norm(conv k3 (x) + bias) * gamma + beta) of a ONE-channel volume with the statistics of a
+    statistics-only conv3d_stem(x, ..., y=None, stats=...) call (inference: no raw output)"""
+    _need_gpu(x, wp, y, stats)
+    N, D, H, W = x.shape[:4]
+    _ck(lib().msseg_conv3d_stem_norm_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(stats), _p(gamma), _p(beta), eps, slope, _p(y), ld(y),
+                                         N, D, H, W, cout, dt(x), _stream()), "conv3d_stem_norm_fwd")
+    return y
+
+
 def conv3d_stem(x, wp, bias, y, cout, stats=None):
-    """conv3d k3 p1 of a ONE-channel volume (bf16, cout % 32 == 0) with optional fused InstanceNorm statistics"""
-    _need_gpu(x, wp, y)
+    """conv3d k3 p1 of a ONE-channel volume (bf16, cout % 32 == 0 or % 48 == 0) with optional fused InstanceNorm statistics;
+    y None (with stats): statistics only"""
+    _need_gpu(x, wp)
     N, D, H, W = x.shape[:4]
     sc = scratch(x.device) if stats is not None else None
-    _ck(lib().msseg_conv3d_stem_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y), N, D, H, W, cout, _p(stats), _p(sc),
+    _ck(lib().msseg_conv3d_stem_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y) if y is not None else 0, N, D, H, W, cout, _p(stats), _p(sc),
                                     sc.numel() if sc is not None else 0, dt(x), _stream()), "conv3d_stem_fwd")
     return y
 

@@ -643,6 +643,18 @@ class ConvNormAct:
 
     def fwd(self, x, out=None, pooled=None):
         cv, nm = self.conv, self.norm
+        if (INFERENCE_FORWARD and pooled is None and cv.cin == 1 and x.dtype == torch.bfloat16 and x.shape[0] <= 8
+                and (cv.cout % 32 == 0 or cv.cout % 48 == 0) and cv.cout <= 256 and not os.environ.get("MSSEG_NO_STEM")
+                and not os.environ.get("MSSEG_NO_STEM_TWICE")):
+            # inference, the one-channel stem unit: a statistics-only launch, then the conv again with InstanceNorm + LeakyReLU
+            # in its epilogue -- the raw output is never written and the normalisation pass over it (read + write of the
+            # largest tensor of the network) disappears; the conv itself reads one channel and is bound by its output write
+            wp = cv.cache.get(cv.w, x.dtype, "g", lambda: hip.pack_conv_gather(cv.w.detach(), x.dtype))
+            stats = torch.empty(x.shape[0], cv.cout, 2, dtype=torch.float32, device=x.device)
+            hip.conv3d_stem(x, wp, cv.b, None, cv.cout, stats)
+            a = out if out is not None else _empty_like_vol(x, cv.cout)
+            hip.conv3d_stem_norm(x, wp, cv.b, stats, nm.gamma, nm.beta, nm.eps, nm.slope, a, cv.cout)
+            return a, (x, None, stats, a)
         if (not cv._gather(x.dtype) and hip.conv3d_k3_small_ok(x, cv.cin, cv.cout)
                 and (pooled is None or hip.instnorm_pool_ok(x, x, pooled))):
             # small grid (12^3 / 6^3 levels): split-K partials + one finish kernel for bias, raw output, statistics,

@@ -1090,6 +1090,34 @@ def test_layer_norm_res_one_node_equals_two_consumers(dtype, C, rows):
         assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("cout,sp,N", [(32, (16, 20, 48), 2), (48, (9, 14, 35), 3), (32, (96, 96, 96), 2)])
+def test_stem_unit_inference_two_launches(cout, sp, N):
+    """inference form of the one-channel conv + InstanceNorm + LeakyReLU unit (statistics-only launch, then the conv again with the
+    normalisation in its epilogue: no raw output) against the training form (conv with fused statistics, normalisation pass)"""
+    from medicalsemseg_amd import layers
+    dev, dtype = _dev(), torch.bfloat16
+    x = cl(gen(N, 1, *sp, seed=1) * 2 + 0.3, dtype, dev)
+    w = torch.nn.Parameter(gen(cout, 1, 3, 3, 3, seed=2, scale=27 ** -0.5).to(dev))
+    b = torch.nn.Parameter(gen(cout, seed=3).to(dev))
+    ga = torch.nn.Parameter((gen(cout, seed=4) * 0.2 + 1).to(dev))
+    be = torch.nn.Parameter((gen(cout, seed=5) * 0.2).to(dev))
+    unit = layers.ConvNormAct(layers.Conv3(w, b), layers.InstNormAct(ga, be, 0.1))
+    a_ref, saved = unit.fwd(x)
+    assert saved[1] is not None                       # the training form keeps the raw output
+    layers.INFERENCE_FORWARD = True
+    try:
+        with torch.no_grad():
+            a_inf, saved_inf = unit.fwd(x)
+    finally:
+        layers.INFERENCE_FORWARD = False
+    assert saved_inf[1] is None                       # no raw output
+    assert torch.equal(saved_inf[2], saved[2])        # the same statistics
+    d = (a_inf.float() - a_ref.float()).abs()
+    # the same arithmetic on the same bf16-rounded conv outputs; at most the last bit where the two compilations contract differently
+    assert float(d.max()) <= 2 ** -7 * float(a_ref.float().abs().max())
+    assert float((d > 0).float().mean()) < 1e-3
+
+
 def test_postproc_kernels_bit_exact(golden_dir):
     """argmax -> uint8, nearest resample (scipy order-0 zoom semantics) and the fold majority vote: bit-exact against the
     numpy oracle, the reference's resample_3d fixture (tests/golden/resample.npz) and ragged sizes"""
