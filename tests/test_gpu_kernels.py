@@ -1427,7 +1427,7 @@ def test_resblock_small_grid_forward_backward(monkeypatch, cin, cout, sp, N):
     assert float((dx_s - dx_t).norm() / dx_t.norm()) < 3e-2
 
 
-@pytest.mark.parametrize("cin,cout,sp", [(96, 48, (32, 32, 48)), (48, 48, (32, 40, 32))])
+@pytest.mark.parametrize("cin,cout,sp", [(96, 48, (32, 32, 48)), (48, 48, (32, 40, 32)), (64, 32, (32, 32, 40))])
 def test_resblock_large_grid_shortcut_gradient_accumulated(monkeypatch, cin, cout, sp):
     """layers.ResBlock backward on grids of the 48-channel ping-pong kernel (Swin-UNETR decoder1 / decoder2 / encoder2): the first
     conv's input gradient is added onto the shortcut's gradient by the kernel's accumulate epilogue instead of a separate add pass --
