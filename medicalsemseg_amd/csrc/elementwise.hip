@@ -1135,12 +1135,21 @@ __global__ __launch_bounds__(256) void conv1x1_head_kernel(const T* __restrict__
 #pragma unroll
         for (int c = 0; c < COUT; ++c) acc[c] = b[c];
         const T* xr = x + v * ldx;
-        for (int k0 = 0; k0 < Cin; k0 += WD) {
-            Chunk<T> xc; xc.load(xr + k0);
+        // the row in pieces of up to four chunks with all loads of a piece issued before the first multiply (a loop of one load
+        // per trip kept 16 bytes in flight per thread: 1.7 TB/s on the 48-channel rows of Swin-UNETR's output block)
+        for (int k0 = 0; k0 < Cin; k0 += 4 * WD) {
+            Chunk<T> xc[4];
 #pragma unroll
-            for (int c = 0; c < COUT; ++c)
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j * WD < Cin) xc[j].load(xr + k0 + j * WD);
 #pragma unroll
-                for (int e = 0; e < WD; ++e) acc[c] += xc.v[e] * wS[c * Cin + k0 + e];
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j * WD < Cin) {
+#pragma unroll
+                    for (int c = 0; c < COUT; ++c)
+#pragma unroll
+                        for (int e = 0; e < WD; ++e) acc[c] += xc[j].v[e] * wS[c * Cin + k0 + j * WD + e];
+                }
         }
         T* yr = y + v * ldy;
 #pragma unroll
