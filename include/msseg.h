@@ -130,6 +130,11 @@ int msseg_zero_stuff2(const void* dy, long long lddy, void* out, long long ldo, 
 int msseg_conv3d_stem_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                           int N, int D, int H, int W, int Cout, float* stats, void* scratch, size_t scratch_bytes,
                           int dtype, msseg_stream_t stream);
+/* ... the 1x1x1 convolution of a one-channel volume (UnetResBlock conv3 of Swin-UNETR's encoder1; wp = the gather image with
+ * K = 1) on the same kernel: centre tap only, same optional statistics */
+int msseg_conv3d_stem_k1_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                             int N, int D, int H, int W, int Cout, float* stats, void* scratch, size_t scratch_bytes,
+                             int dtype, msseg_stream_t stream);
 /* Inference form of the stem unit: y = lrelu(instance_norm(conv(x) + bias) * gamma + beta) with the statistics stats[N][Cout][2]
  * of a statistics-only msseg_conv3d_stem_fwd call in front -- the one-channel conv is cheap enough to run twice, and the raw
  * output's write and the normalisation pass over it disappear (sliding-window inference of BasicUNet at 96^3 windows). */

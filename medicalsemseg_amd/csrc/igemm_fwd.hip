@@ -1045,15 +1045,31 @@ int msseg_conv3d_gather_fwd(const void* x, long long ldx, const void* wp, const 
                               : launch_flat<bf16_t, SRC_GATHER, EPI_STORE>(p, (hipStream_t)stream);
 }
 
+static int stem_fwd_taps(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy, int N, int D,
+                         int H, int W, int Cout, float* stats, void* scratch, size_t scratch_bytes, int dtype, int taps,
+                         msseg_stream_t stream);
+
 int msseg_conv3d_stem_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
                           int N, int D, int H, int W, int Cout, float* stats, void* scratch, size_t scratch_bytes,
                           int dtype, msseg_stream_t stream) {
+    return stem_fwd_taps(x, ldx, wp, bias, y, ldy, N, D, H, W, Cout, stats, scratch, scratch_bytes, dtype, 27, stream);
+}
+
+int msseg_conv3d_stem_k1_fwd(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy,
+                             int N, int D, int H, int W, int Cout, float* stats, void* scratch, size_t scratch_bytes,
+                             int dtype, msseg_stream_t stream) {
+    return stem_fwd_taps(x, ldx, wp, bias, y, ldy, N, D, H, W, Cout, stats, scratch, scratch_bytes, dtype, 1, stream);
+}
+
+static int stem_fwd_taps(const void* x, long long ldx, const void* wp, const float* bias, void* y, long long ldy, int N, int D,
+                         int H, int W, int Cout, float* stats, void* scratch, size_t scratch_bytes, int dtype, int taps,
+                         msseg_stream_t stream) {
     if (!x || !wp || (!y && !stats) || N < 1 || D < 1 || H < 1 || W < 1) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem: bad args");
     if (!msseg_stem_eligible(dtype, 1, Cout, 3, 1, 1, ldx, y ? ldy : 4, y))   // y == NULL: statistics only
         MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem: bf16, Cout a multiple of 32 or 48 (<= 256), 8-byte aligned output rows only");
     StemParams sp{};
     sp.x = x; sp.ldx = ldx; sp.wp = wp; sp.bias = bias; sp.y = y; sp.ldy = ldy;
-    sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.M = Cout;
+    sp.N = N; sp.D = D; sp.H = H; sp.W = W; sp.M = Cout; sp.taps = taps;
     if (stats) {
         if (N > MSSEG_STATS_NMAX) MSSEG_FAIL(MSSEG_EINVAL, "conv3d_stem: fused statistics need N <= %d", MSSEG_STATS_NMAX);
         if (!scratch || ((uintptr_t)scratch & 255) || scratch_bytes < msseg_reduce_scratch_bytes())

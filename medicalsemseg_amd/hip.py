@@ -76,6 +76,7 @@ SIGNATURES = {
     "msseg_linear_gelu_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_linear_gelu_bwd": ([_vp, _ll, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_stem_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
+    "msseg_conv3d_stem_k1_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_stem_norm_fwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_conv3d_k1_head_dgrad_inbwd": ([_vp, _ll, _vp, _vp, _ll, _i, _ll, _i, _i, _vp, _ll, _vp, _vp, _vp, _f, _f, _vp, _vp,
                                           _vp, _i, _vp, _sz, _i, _vp], _i),
@@ -732,13 +733,14 @@ def conv3d_stem_norm(x, wp, bias, stats, gamma, beta, eps, slope, y, cout):
     return y
 
 
-def conv3d_stem(x, wp, bias, y, cout, stats=None):
-    """conv3d k3 p1 of a ONE-channel volume (bf16, cout % 32 == 0 or % 48 == 0) with optional fused InstanceNorm statistics;
-    y None (with stats): statistics only"""
+def conv3d_stem(x, wp, bias, y, cout, stats=None, k=3):
+    """conv3d k3 p1 (k = 1: the 1x1x1 conv, image with K = 1) of a ONE-channel volume (bf16, cout % 32 == 0 or % 48 == 0) with
+    optional fused InstanceNorm statistics; y None (with stats): statistics only"""
     _need_gpu(x, wp)
     N, D, H, W = x.shape[:4]
     sc = scratch(x.device) if stats is not None else None
-    _ck(lib().msseg_conv3d_stem_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y) if y is not None else 0, N, D, H, W, cout, _p(stats), _p(sc),
+    fn = lib().msseg_conv3d_stem_fwd if k == 3 else lib().msseg_conv3d_stem_k1_fwd
+    _ck(fn(_p(x), ld(x), _p(wp), _p(bias), _p(y), ld(y) if y is not None else 0, N, D, H, W, cout, _p(stats), _p(sc),
                                     sc.numel() if sc is not None else 0, dt(x), _stream()), "conv3d_stem_fwd")
     return y
 

@@ -427,6 +427,12 @@ class Conv1:
         y = out if out is not None else _empty_like_vol(x, self.cout)
         if self._gather(dtype):
             wp = self.cache.get(self.w, dtype, "g", lambda: hip.pack_conv_gather(self.w.detach(), dtype))
+            if (want_stats and self.cin == 1 and dtype == torch.bfloat16 and x.dim() == 5 and x.shape[0] <= 8 and hip.ld(y) == self.cout
+                    and (self.cout % 32 == 0 or self.cout % 48 == 0) and self.cout <= 256 and not os.environ.get("MSSEG_NO_STEM")):
+                # the shortcut conv on the one-channel input: stem kernel (centre tap) with the statistics fused
+                stats = torch.empty(x.shape[0], self.cout, 2, dtype=torch.float32, device=x.device)
+                hip.conv3d_stem(x, wp, self.b, y, self.cout, stats, k=1)
+                return y, stats
             hip.conv3d_gather(x, wp, self.b, y, self.cin, self.cout, 1, 1, 0)
         elif (self.cout <= 4 and self.cin <= 64 and x.shape[-1] == self.cin and self.w.is_contiguous()
               and not os.environ.get("MSSEG_NO_HEAD_KERNEL")):

@@ -159,6 +159,15 @@ def test_conv3d_gather(dtype, cin, cout, k, s, p, sp):
     dw = torch.empty(cout, cin, k, k, k, device=dev)
     hip.conv3d_gather_wgrad(xg, cl(dy, dtype, dev), dw, cin, cout, k, s, p)
     check(dw, wr.grad, dtype, "gather wgrad")
+    if cin == 1 and k == 1 and dtype == torch.bfloat16:
+        # the same conv through the stem entry point with fused InstanceNorm statistics (layers.Conv1.fwd(want_stats))
+        y2 = torch.empty_like(y)
+        stats = torch.full((N, cout, 2), float("nan"), device=dev)
+        hip.conv3d_stem(xg, wp, b.to(dev), y2, cout, stats, k=1)
+        assert torch.equal(y2, y)
+        yf = y.float().reshape(N, -1, cout)
+        ref = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)
+        assert float((stats - ref).abs().max()) / float(ref.abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("cout,sp,N", [(32, (16, 16, 16), 2), (64, (10, 13, 21), 3), (32, (33, 20, 48), 2),
