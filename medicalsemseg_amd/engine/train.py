@@ -86,6 +86,10 @@ class _GraphedFwdBwd:
             self.graph_tail = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_tail, pool=self.graph.pool()):
                 tail()
+        # FlatAdamW's lazy zero_grad: the captured kernels overwrite the gradients they produce; a replay runs no Python, so
+        # the parameters written during the capture are marked as written after every replay (optim.FlatAdamW.mark_written)
+        self.optimizer = weakref.ref(optimizer)
+        self.written = optimizer.written_params() if hasattr(optimizer, "written_params") else None
 
     def __call__(self, inputs, labels, between=None):
         self.x.copy_(inputs)
@@ -98,6 +102,9 @@ class _GraphedFwdBwd:
         crit = self.criterion()
         if crit is not None and hasattr(crit, "last"):
             crit.last.update(self.last)
+        opt = self.optimizer()
+        if opt is not None and self.written is not None:
+            opt.mark_written(self.written)
         return self.out, self.loss
 
 

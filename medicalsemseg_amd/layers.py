@@ -217,9 +217,23 @@ APPLIED = _Applied()
 
 
 def _grad_buf(p: torch.nn.Parameter):
-    """(tensor to write the gradient into, accumulate?)"""
+    """(tensor to write the gradient into, accumulate?)
+
+    Parameters whose gradient buffer belongs to an optimiser with a LAZY zero_grad (optim.FlatAdamW: `p._msseg_gowner`): the first
+    kernel that produces the parameter's gradient after a zero_grad() OVERWRITES the buffer (accumulate False), later ones in the
+    same epoch add.  The zero fill of the flat gradient buffer (310 MB per step for Swin-UNETR-48) and the read of the zeros by
+    every first accumulation disappear; parameters no kernel touched in an epoch are zeroed by the optimiser before it reads
+    the buffer (FlatAdamW._zero_untouched)."""
     if p.grad is None:
         p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
+        return p.grad, False
+    owner = getattr(p, "_msseg_gowner", None)
+    if owner is not None and not getattr(p, "_msseg_kgrad", False):
+        p._msseg_kgrad = True      # from now on this gradient is kernel-written: the optimiser stops zero-filling its slice
+        p._msseg_gepoch = owner._gepoch
+        return p.grad, True        # (this epoch it still was)
+    if owner is not None and getattr(p, "_msseg_gepoch", -1) != owner._gepoch:
+        p._msseg_gepoch = owner._gepoch
         return p.grad, False
     return p.grad, True
 
@@ -363,8 +377,10 @@ class Conv3:
             if bias_grad_is_zero:
                 # a bias feeding InstanceNorm: d loss / d bias == 0 identically (the mean subtraction removes it);
                 # dy sums to zero over every (n, c) by construction of the InstanceNorm backward
-                if not acc:
+                # (with a lazily zeroed buffer the fill runs once: nothing else ever writes this gradient)
+                if not acc and not getattr(self.b, "_msseg_grad_is_zero", False):
                     g.zero_()
+                    self.b._msseg_grad_is_zero = getattr(self.b, "_msseg_gowner", None) is not None
             else:
                 hip.channel_sum(dy, g, acc)
         if not need_dx:

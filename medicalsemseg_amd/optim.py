@@ -12,6 +12,7 @@
 from __future__ import annotations
 
 import math
+import os
 from typing import Iterable, List
 
 import torch
@@ -68,6 +69,14 @@ class FlatAdamW(torch.optim.Optimizer):
                     off += k
         self._n = n
         self._step = 0
+        # lazy zero_grad (layers._grad_buf): gradients live in flat_grad for good, zero_grad() only opens a new epoch
+        # (MSSEG_EAGER_ZERO_GRAD=1: zero_grad() fills the buffer and every kernel accumulates, as torch's set_to_none=False does.
+        #  Between a lazy zero_grad() and the next backward the gradient views hold the previous step's values, not zeros.)
+        self._gepoch = 0
+        if not os.environ.get("MSSEG_EAGER_ZERO_GRAD"):
+            for p, _ in self._views:
+                p._msseg_gowner = self
+                p._msseg_gepoch = -1
         self._gscale = torch.ones(1, dtype=torch.float32, device=dev)
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
         # device-resident (lr, step): the fused kernel reads them, so a captured hipGraph replays correctly
@@ -81,14 +90,63 @@ class FlatAdamW(torch.optim.Optimizer):
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
                 if p.grad is not None:
                     gv.copy_(p.grad)
+                    p._msseg_gepoch = getattr(self, "_gepoch", 0)   # a gradient made elsewhere: counts as written this epoch
                 p.grad = gv
 
     def zero_grad(self, set_to_none: bool = False):
-        # gradients are overwritten/accumulated in place in the flat buffer: zero it and keep the views bound
-        self.flat_grad.zero_()
+        # gradients are overwritten / accumulated in place in the flat buffer and the views stay bound.  No fill: a new epoch --
+        # the first kernel that writes a parameter's gradient in it overwrites (layers._grad_buf); whatever no kernel touched is
+        # zeroed before the buffer is read (_zero_untouched)
+        self._gepoch += 1
         self.attach_grads()
+        if os.environ.get("MSSEG_EAGER_ZERO_GRAD"):
+            self.flat_grad.zero_()
+            return
+        # gradients that torch autograd accumulates into (parameters no kernel of this package has ever written: a torch encoder
+        # in front of the UNETR decoder, ...) still need their zeros: contiguous runs of such slices, none for the models here
+        for a, b in self._autograd_ranges():
+            self.flat_grad[a:b].zero_()
+
+    def _autograd_ranges(self):
+        n_k = sum(1 for p, _ in self._views if getattr(p, "_msseg_kgrad", False))
+        if getattr(self, "_ar_key", None) != n_k:
+            runs, off, start = [], 0, None
+            for p, _ in self._views:
+                k = p.numel()
+                if not getattr(p, "_msseg_kgrad", False):
+                    start = off if start is None else start
+                elif start is not None:
+                    runs.append((start, off)); start = None
+                off += k
+            if start is not None:
+                runs.append((start, off))
+            self._ar_key, self._ar = n_k, runs
+        for p, _ in self._views:
+            if not getattr(p, "_msseg_kgrad", False):
+                p._msseg_gepoch = self._gepoch      # zeroed just now; autograd adds into it
+        return self._ar
+
+    def written_params(self):
+        """parameters whose gradient a kernel wrote since the last zero_grad() (for callers that replay captured launches)"""
+        return [p for p, _ in self._views if getattr(p, "_msseg_gepoch", -1) == self._gepoch]
+
+    def mark_written(self, params):
+        """a replayed hipGraph wrote these parameters' gradients (the capture's launches overwrite them; no Python ran)"""
+        for p in params:
+            p._msseg_gepoch = self._gepoch
+
+    def _zero_untouched(self):
+        """gradients no kernel wrote since the last zero_grad(): zero them now (normally none: no launch)"""
+        for p, gv in self._views:
+            # only gradients that this package's kernels write (they overwrite on first touch, so nothing has cleared the slice);
+            # everything else -- torch autograd's in-place accumulation, a caller filling .grad by hand -- was zero-filled by
+            # zero_grad() and must be left alone
+            if getattr(p, "_msseg_kgrad", False) and getattr(p, "_msseg_gepoch", -1) != self._gepoch:
+                gv.zero_()
+                p._msseg_gepoch = self._gepoch
 
     def grad_norm(self) -> torch.Tensor:
+        self._zero_untouched()
         self._sq.zero_()
         hip.sumsq(self.flat_grad, self._sq)
         return self._sq.sqrt()
@@ -168,6 +226,7 @@ class FlatAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         self.attach_grads()
+        self._zero_untouched()
         self._step += 1
         self.sync_lr()
         lr = self.param_groups[0]["lr"]
