@@ -140,8 +140,19 @@ __global__ __launch_bounds__(256) void dice_ce_rows_finalize_kernel(const float*
         for (int c0 = 0; c0 < L; c0 += cols) {
             const int col = threadIdx.x % cols, rg = threadIdx.x / cols, o = c0 + col;
             float s = 0.f;
-            if (o < L && rg < G)
-                for (int b = rg; b < nblk; b += G) s += base[(long long)b * L + o];
+            if (o < L && rg < G) {
+                // eight rows in flight per thread (the adds stay in row order: same sum); a loop of one load per trip paid the
+                // memory latency 36 times over: 20 us for 432 rows per sample
+                int b = rg;
+                for (; b + 7 * G < nblk; b += 8 * G) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = base[(long long)(b + j * G) * L + o];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s += v[j];
+                }
+                for (; b < nblk; b += G) s += base[(long long)b * L + o];
+            }
             __syncthreads();
             fin[threadIdx.x] = s;
             __syncthreads();
