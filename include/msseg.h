@@ -459,6 +459,13 @@ int msseg_linear_gelu_fwd(const void* x, long long ldx, const void* wp, const fl
                           long long ldact, long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
 int msseg_linear_gelu_bwd(const void* dy, long long lddy, const void* wp, const void* pre, long long ldpre, void* dpre,
                           long long lddpre, long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
+/* nn.Linear with the residual add of a Swin block in its epilogue: y = res + (x W^T + b), the sum formed from the bf16-rounded
+ * Linear output exactly as Linear followed by an add pass forms it (/root/reference/models/backbones/swin_nnformer.py:243-262:
+ * x = shortcut + proj(attn), x = x + mlp(norm2(x))).  msseg_linear_add_ok() == 1 for the shapes the register-resident-weight
+ * kernel takes. */
+int msseg_linear_add_ok(long long NV, int Cin, int Cout, int dtype);
+int msseg_linear_add_fwd(const void* x, long long ldx, const void* wp, const float* bias, const void* res, long long ldres,
+                         void* y, long long ldy, long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dice + cross-entropy loss (MONAI DiceCELoss(to_onehot_y, softmax, squared_pred) as built at

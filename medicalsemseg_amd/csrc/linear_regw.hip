@@ -19,6 +19,8 @@
 // applied to the 16-byte output chunks on their way from the LDS tile to memory:
 //   EPI_GELU      y = the pre-activation, y2 = gelu(y as stored): fc1 + GELU forward without the separate pass that re-reads it
 //   EPI_GELU_BWD  y = (dy W) as stored * gelu'(aux): the input gradient of fc2 straight into the gradient of fc1's output
+//   EPI_ADD       y = aux + (x W + b) as stored: the residual add behind the attention projection / fc2 of a Swin block
+//                 (swin_nnformer.py:243-262) without the separate add pass
 // with the arithmetic of gelu_kernel (attention.hip) on the bf16-rounded operands, i.e. bit-identical to the unfused chain.
 #include "k3pp.h"
 
@@ -39,7 +41,7 @@ struct LinParams {
     const void* aux; long long ldaux;   // EPI_GELU_BWD: the pre-activation of the layer that receives this gradient
 };
 
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GELU_BWD = 2 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GELU_BWD = 2, EPI_ADD = 3 };
 
 MSSEG_DEVFN float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 MSSEG_DEVFN float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
@@ -120,6 +122,11 @@ __global__ __launch_bounds__(LR_THREADS, 2) void linear_regw_kernel(const LinPar
                         const float g1 = bf16_hi(o[w]) * (gelu_cdf(a1) + a1 * 0.3989422804014327f * expf(-0.5f * a1 * a1));
                         o[w] = pack_bf16x2(g0, g1);
                     }
+                }
+                if constexpr (EPI == EPI_ADD) {   // the unfused chain's arithmetic: the Linear output rounded to bf16, then the add
+                    const u32x4_t a = *(const u32x4_t*)((const bf16_t*)p.aux + mbase + (v0 + vv) * p.ldaux + part * 8);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) o[w] = pack_bf16x2(bf16_lo(a[w]) + bf16_lo(o[w]), bf16_hi(a[w]) + bf16_hi(o[w]));
                 }
                 *(u32x4_t*)(yg + (v0 + vv) * p.ldy + part * 8) = o;
                 if constexpr (EPI == EPI_GELU) {
@@ -227,15 +234,15 @@ int pick_nh(int ks, int Cout) {
     return 0;
 }
 
-template <int KS> int launch_ks(const LinParams& p, int nh, int slices, hipStream_t stream) {
+template <int KS, int EPI = EPI_NONE> int launch_ks(const LinParams& p, int nh, int slices, hipStream_t stream) {
     switch (nh) {
-        case 1: return launch<KS, 1>(p, slices, stream);
-        case 2: if constexpr (KS * 2 <= MAX_FRAGS) return launch<KS, 2>(p, slices, stream); break;
-        case 3: if constexpr (KS * 3 <= MAX_FRAGS) return launch<KS, 3>(p, slices, stream); break;
-        case 4: if constexpr (KS * 4 <= MAX_FRAGS) return launch<KS, 4>(p, slices, stream); break;
-        case 6: if constexpr (KS * 6 <= MAX_FRAGS) return launch<KS, 6>(p, slices, stream); break;
-        case 9: if constexpr (KS * 9 <= MAX_FRAGS) return launch<KS, 9>(p, slices, stream); break;
-        case 12: if constexpr (KS * 12 <= MAX_FRAGS) return launch<KS, 12>(p, slices, stream); break;
+        case 1: return launch<KS, 1, EPI>(p, slices, stream);
+        case 2: if constexpr (KS * 2 <= MAX_FRAGS) return launch<KS, 2, EPI>(p, slices, stream); break;
+        case 3: if constexpr (KS * 3 <= MAX_FRAGS) return launch<KS, 3, EPI>(p, slices, stream); break;
+        case 4: if constexpr (KS * 4 <= MAX_FRAGS) return launch<KS, 4, EPI>(p, slices, stream); break;
+        case 6: if constexpr (KS * 6 <= MAX_FRAGS) return launch<KS, 6, EPI>(p, slices, stream); break;
+        case 9: if constexpr (KS * 9 <= MAX_FRAGS) return launch<KS, 9, EPI>(p, slices, stream); break;
+        case 12: if constexpr (KS * 12 <= MAX_FRAGS) return launch<KS, 12, EPI>(p, slices, stream); break;
     }
     MSSEG_FAIL(MSSEG_EINVAL, "linear_regw: no instantiation for %d k-steps x %d output tiles", KS, nh);
 }
@@ -330,6 +337,40 @@ int msseg_linear_gelu_fwd(const void* x, long long ldx, const void* wp, const fl
     int ks, nh;
     lr_gelu_shape(Cin, Cout, &ks, &nh);
     return launch_gelu<EPI_GELU>(p, ks, nh, Cout, (hipStream_t)stream);
+}
+
+/* y = res + (x W^T + b): nn.Linear with the residual add of a Swin block in its epilogue (the sum of the bf16-rounded Linear
+ * output and res, as the unfused chain forms it).  msseg_linear_add_ok() == 1 for the widths of the register-resident-weight
+ * kernel (Cin <= 768 at the Swin widths); callers keep Linear + add otherwise. */
+int msseg_linear_add_ok(long long NV, int Cin, int Cout, int dtype) {
+    static const bool off = getenv("MSSEG_NO_LINEAR_ADD") != nullptr || getenv("MSSEG_NO_LINEAR_REGW") != nullptr;   // A/B switch
+    if (off || dtype != MSSEG_BF16 || NV < 1 || Cout % 16 || Cin % 8) return 0;
+    const int ks = (Cin + 31) / 32;
+    return (lr_ks_ok(ks) && pick_nh(ks, Cout) != 0) ? 1 : 0;
+}
+
+int msseg_linear_add_fwd(const void* x, long long ldx, const void* wp, const float* bias, const void* res, long long ldres, void* y,
+                         long long ldy, long long NV, int Cin, int Cout, int dtype, msseg_stream_t stream) {
+    if (!x || !wp || !y || !res) MSSEG_FAIL(MSSEG_EINVAL, "linear_add_fwd: null pointer");
+    if (!msseg_linear_add_ok(NV, Cin, Cout, dtype)) MSSEG_FAIL(MSSEG_EINVAL, "linear_add_fwd: shape %d -> %d not supported (msseg_linear_add_ok)", Cin, Cout);
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)res & 15) || ((uintptr_t)wp & 15) || (ldx % 8) || (ldy % 8) || (ldres % 8) ||
+        ldx < Cin || ldy < Cout || ldres < Cout || (bias && ((uintptr_t)bias & 15)))
+        MSSEG_FAIL(MSSEG_EINVAL, "linear_add_fwd: operands must be 16-byte aligned with strides that are multiples of 8 elements");
+    LinParams p{};
+    p.x = x; p.ldx = ldx; p.wp = wp; p.bias = bias; p.y = y; p.ldy = ldy; p.aux = res; p.ldaux = ldres; p.NV = NV; p.K = Cin;
+    p.cb = msseg_cout_block(Cout);
+    const int ks = (Cin + 31) / 32, nh = pick_nh(ks, Cout), slices = Cout / (nh * 16);
+    hipStream_t st = (hipStream_t)stream;
+    switch (ks) {
+        case 2: return launch_ks<2, EPI_ADD>(p, nh, slices, st);
+        case 3: return launch_ks<3, EPI_ADD>(p, nh, slices, st);
+        case 5: return launch_ks<5, EPI_ADD>(p, nh, slices, st);
+        case 6: return launch_ks<6, EPI_ADD>(p, nh, slices, st);
+        case 9: return launch_ks<9, EPI_ADD>(p, nh, slices, st);
+        case 12: return launch_ks<12, EPI_ADD>(p, nh, slices, st);
+        case 18: return launch_ks<18, EPI_ADD>(p, nh, slices, st);
+        default: return launch_ks<24, EPI_ADD>(p, nh, slices, st);
+    }
 }
 
 int msseg_linear_gelu_bwd(const void* dy, long long lddy, const void* wp, const void* pre, long long ldpre, void* dpre,

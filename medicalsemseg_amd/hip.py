@@ -75,6 +75,8 @@ SIGNATURES = {
     "msseg_linear_gelu_ok": ([_ll, _i, _i, _i], _i),
     "msseg_linear_gelu_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_linear_gelu_bwd": ([_vp, _ll, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
+    "msseg_linear_add_ok": ([_ll, _i, _i, _i], _i),
+    "msseg_linear_add_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _ll, _i, _i, _i, _vp], _i),
     "msseg_conv3d_stem_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_stem_k1_fwd": ([_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp], _i),
     "msseg_conv3d_stem_norm_fwd": ([_vp, _ll, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -1423,6 +1425,24 @@ def linear_gelu_bwd(dy, wp, pre, dpre, cin, cout):
                  lambda: _ck(lib().msseg_linear_gelu_bwd(_p(dy), ld(dy), _p(wp), _p(pre), ld(pre), _p(dpre), ld(dpre), nv, cin,
                                                          cout, dt(dy), _stream()), "linear_gelu_bwd"))
     return dpre
+
+
+def linear_add_ok(x, res, cin, cout) -> bool:
+    """can y = res + Linear(x) run as one launch (bf16, shapes of the register-resident-weight kernel, aligned operands)?"""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and res.dtype == x.dtype and x.data_ptr() % 16 == 0 and res.data_ptr() % 16 == 0):
+        return False
+    return bool(lib().msseg_linear_add_ok(x.numel() // x.shape[-1], cin, cout, BF16))
+
+
+def linear_add(x, wp, bias, res, y, cin, cout):
+    """y = res + (x W^T + b) (the bf16-rounded Linear output added to res: bit-identical to conv3d_k1 followed by an add pass)"""
+    _need_gpu(x, wp, res, y)
+    nv = x.numel() // x.shape[-1]
+    esz = x.element_size()
+    TIMER.launch("linear_add_fwd", 2.0 * nv * cin * cout, nv * (cin + 2 * cout) * esz + cin * cout * esz,
+                 lambda: _ck(lib().msseg_linear_add_fwd(_p(x), ld(x), _p(wp), _p(bias), _p(res), ld(res), _p(y), ld(y), nv, cin, cout,
+                                                        dt(x), _stream()), "linear_add_fwd"))
+    return y
 
 
 def gelu_bwd(x, dy, dx):

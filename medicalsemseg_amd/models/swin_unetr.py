@@ -253,14 +253,18 @@ class _Block(nn.Module):
         x, xn = ops.layer_norm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)   # x: the residual, through the node
         qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias)
         y = ops.WindowAttnFn.apply(qkv, a.qkv.bias, a.relative_position_bias_table, self.heads, self.ws, self.shift)
-        y = ops.linear(y, a.proj.weight, a.proj.bias)
-        x = ops.add(x, y, self._dp_scale(x))
-        x, y = ops.layer_norm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        if isinstance(self.mlp, (_DepthMlp, _InceptionMlp)):
-            y = self.mlp.run(y)
+        dp = self._dp_scale(x)
+        if dp is None:     # no stochastic depth in this step: the residual adds ride on the Linear kernels' epilogues
+            x = ops.linear_add(y, a.proj.weight, a.proj.bias, x)
         else:
-            y = ops.mlp(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias)
-        return ops.add(x, y, self._dp_scale(x))
+            x = ops.add(x, ops.linear(y, a.proj.weight, a.proj.bias), dp)
+        x, y = ops.layer_norm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        dp = self._dp_scale(x)
+        if isinstance(self.mlp, (_DepthMlp, _InceptionMlp)):
+            return ops.add(x, self.mlp.run(y), dp)
+        if dp is None:
+            return ops.mlp(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, res=x)
+        return ops.add(x, ops.mlp(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias), dp)
 
 
 class _PatchMerging(nn.Module):

@@ -76,11 +76,9 @@ class _Block(nn.Module):
         y = ops.WindowAttnFn.apply(qkv, a.qkv.bias, a.relative_position_bias_table, self.heads, ws, shift, a.ws)
         if pad:
             y = ops.box_resize(y, (d, h, w))
-        y = ops.linear(y, a.proj.weight, a.proj.bias)   # per-token: commutes with the crop
-        x = ops.add(x, y)
+        x = ops.linear_add(y, a.proj.weight, a.proj.bias, x)   # per-token: commutes with the crop; residual add in the epilogue
         x, y = ops.layer_norm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        y = ops.mlp(y, self.mlp.linear1.weight, self.mlp.linear1.bias, self.mlp.linear2.weight, self.mlp.linear2.bias)
-        return ops.add(x, y)
+        return ops.mlp(y, self.mlp.linear1.weight, self.mlp.linear1.bias, self.mlp.linear2.weight, self.mlp.linear2.bias, res=x)
 
 
 class _PatchMerging(nn.Module):

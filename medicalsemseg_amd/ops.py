@@ -78,6 +78,46 @@ class LinearFn(torch.autograd.Function):
         return dx, None, None
 
 
+class LinearAddFn(torch.autograd.Function):
+    """res + Linear(x): the attention projection of a Swin block with the residual add in the Linear kernel's epilogue
+    (hip.linear_add_ok shapes; bit-identical to linear followed by add)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res):
+        x, res = _c(x), _c(res)
+        cout, cin = weight.shape[:2]
+        T = x.dtype
+        wp = _packed(weight, T, "f", lambda: hip.pack_conv_k1(weight.detach().reshape(cout, cin), T))
+        y = torch.empty(x.shape[:-1] + (cout,), dtype=T, device=x.device)
+        hip.linear_add(x, wp, bias, res, y, cin, cout)
+        ctx.save_for_backward(x)
+        ctx.weight, ctx.bias = weight, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        dy = _c(dy)
+        cout, cin = weight.shape[:2]
+        T = x.dtype
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wpd = _packed(weight, T, "d", lambda: hip.pack_conv_k1(weight.detach().reshape(cout, cin), T, dgrad=True))
+            dx = torch.empty_like(x)
+            hip.conv3d_k1(dy, wpd, None, dx, cout, cin)
+        _linear_param_grads(x, dy, weight, bias, cin, cout, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return dx, None, None, dy
+
+
+def linear_add(x, weight, bias, res):
+    """res + linear(x, weight, bias): one launch where the fused kernel takes the shape, linear + add otherwise"""
+    cout, cin = weight.shape[:2]
+    if x.is_cuda and res.shape[:-1] == x.shape[:-1] and res.shape[-1] == cout and hip.linear_add_ok(x, res, cin, cout):
+        return LinearAddFn.apply(x, weight, bias, res)
+    return add(res, linear(x, weight, bias))
+
+
 class MlpFn(torch.autograd.Function):
     """fc2(gelu(fc1(x))) -- the MLP of a Swin block (/root/reference/models/backbones/swin_nnformer.py:24-42) -- as ONE
     autograd node, so that the GELU rides on the Linear kernels' epilogues: forward fc1 writes the pre-activation and the
@@ -86,7 +126,9 @@ class MlpFn(torch.autograd.Function):
     kernel does not take (hip.linear_gelu_ok) run the three kernels."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, res=None):
+        """res (optional, shaped like the output): the result is res + fc2(...), the add in fc2's epilogue where the kernel takes
+        the shape (hip.linear_add_ok), a separate add pass otherwise"""
         x = _c(x)
         chid, cin = w1.shape[:2]
         cout = w2.shape[0]
@@ -102,7 +144,21 @@ class MlpFn(torch.autograd.Function):
             hip.conv3d_k1(x, wp1, b1, pre, cin, chid)
             hip.gelu_fwd(pre, act)
         y = torch.empty(x.shape[:-1] + (cout,), dtype=T, device=x.device)
-        hip.conv3d_k1(act, wp2, b2, y, chid, cout)
+        ctx.has_res = res is not None
+        if res is not None:
+            res = _c(res)
+            if hip.linear_add_ok(act, res, chid, cout):
+                hip.linear_add(act, wp2, b2, res, y, chid, cout)
+            else:
+                hip.conv3d_k1(act, wp2, b2, y, chid, cout)
+                lin, y = y, torch.empty_like(y)
+                epc = 16 // y.element_size()
+                if (y.numel() // y.shape[0]) % epc == 0 and res.data_ptr() % 16 == 0:
+                    hip.axpy_rows(res, lin, None, y)
+                else:
+                    hip.add(res, lin, y)
+        else:
+            hip.conv3d_k1(act, wp2, b2, y, chid, cout)
         ctx.save_for_backward(x, pre, act)
         ctx.params = (w1, b1, w2, b2)
         return y
@@ -130,7 +186,7 @@ class MlpFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             hip.conv3d_k1(dpre, wpd1, None, dx, chid, cin)
         _linear_param_grads(x, dpre, w1, b1, cin, chid, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-        return dx, None, None, None, None
+        return dx, None, None, None, None, (dy if ctx.has_res else None)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -633,9 +689,9 @@ def gelu(x):
     return GeluFn.apply(x)
 
 
-def mlp(x, w1, b1, w2, b2):
-    """fc2(gelu(fc1(x))) with the GELU fused into the Linear kernels where the shape allows (MlpFn)"""
-    return MlpFn.apply(x, w1, b1, w2, b2)
+def mlp(x, w1, b1, w2, b2, res=None):
+    """fc2(gelu(fc1(x))) [+ res] with the GELU (and the residual add) fused into the Linear kernels where the shape allows (MlpFn)"""
+    return MlpFn.apply(x, w1, b1, w2, b2, res)
 
 
 def add(a, b, scale=None):

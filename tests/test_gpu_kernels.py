@@ -1127,6 +1127,43 @@ def test_stem_unit_inference_two_launches(cout, sp, N):
     assert float((d > 0).float().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("cin,cout,tokens", [(48, 48, 1000), (192, 48, 777), (384, 96, 432), (768, 192, 100), (1536, 384, 54)])
+def test_linear_add_and_mlp_residual_fused_equal_unfused(cin, cout, tokens):
+    """res + Linear(x) with the add in the Linear kernel's epilogue (ops.linear_add, ops.mlp(res=)) == linear / mlp followed by
+    ops.add, bit for bit, values and gradients (the last shape takes the unfused fallback: K = 1536 runs on the K-split kernel)"""
+    from medicalsemseg_amd import ops
+    dev, dtype = _dev(), torch.bfloat16
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.randn(2, tokens, 1, 1, cin, generator=g).to(dev, dtype)
+    r0 = torch.randn(2, tokens, 1, 1, cout, generator=g).to(dev, dtype)
+    w = torch.nn.Parameter((torch.randn(cout, cin, generator=g) * cin ** -0.5).to(dev))
+    b = torch.nn.Parameter((torch.randn(cout, generator=g) * 0.1).to(dev))
+    gy = torch.randn(r0.shape, generator=g).to(dev, dtype)
+    res = []
+    for fused in (True, False):
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        w.grad = b.grad = None
+        y = ops.linear_add(x, w, b, r) if fused else ops.add(r, ops.linear(x, w, b))
+        y.backward(gy)
+        res.append((y.detach().clone(), x.grad.clone(), r.grad.clone(), w.grad.clone(), b.grad.clone()))
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
+    if cin == 4 * cout:    # the MLP of a Swin block with the residual: x -> fc1 (cout -> cin) -> GELU -> fc2 (cin -> cout) + res
+        w1 = torch.nn.Parameter((torch.randn(cin, cout, generator=g) * cout ** -0.5).to(dev))
+        b1 = torch.nn.Parameter((torch.randn(cin, generator=g) * 0.1).to(dev))
+        res = []
+        for fused in (True, False):
+            x = r0.clone().requires_grad_(True)
+            for p_ in (w, b, w1, b1):
+                p_.grad = None
+            xr, xn = ops.layer_norm_res(x, None, None, 1e-5)
+            y = ops.mlp(xn, w1, b1, w, b, res=xr) if fused else ops.add(xr, ops.mlp(xn, w1, b1, w, b))
+            y.backward(gy)
+            res.append((y.detach().clone(), x.grad.clone(), w.grad.clone(), w1.grad.clone()))
+        for a_, b_ in zip(res[0], res[1]):
+            assert torch.equal(a_, b_)
+
+
 def test_postproc_kernels_bit_exact(golden_dir):
     """argmax -> uint8, nearest resample (scipy order-0 zoom semantics) and the fold majority vote: bit-exact against the
     numpy oracle, the reference's resample_3d fixture (tests/golden/resample.npz) and ragged sizes"""
