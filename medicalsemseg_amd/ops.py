@@ -310,9 +310,23 @@ class BoxCopyFn(torch.autograd.Function):
         return hip.box_copy(dy, dx), None
 
 
+def _chunked(x) -> bool:
+    """channel count a multiple of the 16-byte chunk and a 16-byte aligned base: what the layout kernels need (GPU tensors only:
+    there is no CPU path)"""
+    if not x.is_cuda:
+        raise RuntimeError("medicalsemseg_amd ops run on the GPU only (no CPU fallback)")
+    return x.shape[-1] % (16 // x.element_size()) == 0 and x.data_ptr() % 16 == 0
+
+
 def box_resize(x, size):
     """x zero-padded (at the high end) or cropped to the spatial size `size`"""
-    return BoxCopyFn.apply(x, tuple(int(v) for v in size))
+    size = tuple(int(v) for v in size)
+    if not _chunked(x):      # odd channel counts: the torch ops this replaces
+        d, h, w = x.shape[1:4]
+        if all(s >= v for s, v in zip(size, (d, h, w))):
+            return torch.nn.functional.pad(x, (0, 0, 0, size[2] - w, 0, size[1] - h, 0, size[0] - d))
+        return x[:, :size[0], :size[1], :size[2], :].contiguous()
+    return BoxCopyFn.apply(x, size)
 
 
 class MergeGatherFn(torch.autograd.Function):
@@ -335,6 +349,10 @@ class MergeGatherFn(torch.autograd.Function):
 
 
 def merge_gather(x, offsets):
+    if not _chunked(x):      # odd channel counts: the torch ops this replaces
+        d, h, w = x.shape[1:4]
+        xp = torch.nn.functional.pad(x, (0, 0, 0, w % 2, 0, h % 2, 0, d % 2))
+        return torch.cat([xp[:, a::2, b::2, c::2, :] for a, b, c in offsets], -1)
     return MergeGatherFn.apply(x, tuple(tuple(o) for o in offsets))
 
 
