@@ -95,7 +95,7 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = q * 8 + j;
-        toff[j] = ntaps == 1 ? (PH + 1) * PW + 1 : ((k < 27) ? ((k / 9) * PH + ((k / 3) % 3)) * PW + (k % 3) : 0);
+        toff[j] = ntaps == 1 ? (PH + 1) * PW + 1 : ((k < 27) ? ((k / 9) * PH + ((k / 3) % 3)) * PW + (k % 3) : 0);   // k >= taps: any valid element
     }
     if (STATS) {
         for (int i = tid; i < F_STAT_FLOATS; i += F_THREADS) ldsS[i] = 0.f;
@@ -191,12 +191,12 @@ __global__ __launch_bounds__(F_THREADS) void stem_fwd_kernel(const StemParams p)
             unsigned short v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = hb[base + toff[j]];
+            // k-slots past the last tap read a valid halo element (toff = that of tap 0) against a ZERO weight: the packed image
+            // is zero-filled beyond K, so no masking of the operand is needed (a non-finite input there already reaches this
+            // voxel through tap 0)
             u32x4_t xf;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned lo = (q * 8 + 2 * j < ntaps) ? v[2 * j] : 0u, hi = (q * 8 + 2 * j + 1 < ntaps) ? v[2 * j + 1] : 0u;
-                xf[j] = lo | (hi << 16);
-            }
+            for (int j = 0; j < 4; ++j) xf[j] = (unsigned)v[2 * j] | ((unsigned)v[2 * j + 1] << 16);
             const int d = tc.d0 + dw, h = tc.h0 + hrow, w = tc.w0 + r;
             const bool ok = d < p.D && h < p.H && w < p.W;
             const long long vox = (((long long)tc.n * p.D + d) * p.H + h) * p.W + w;
