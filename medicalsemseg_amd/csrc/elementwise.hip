@@ -1249,14 +1249,33 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* out) {
+// Sum of squares (the gradient norm of clip_grad_norm_) in a fixed order: per-block partials, then one block adds them.  The float
+// atomicAdd this replaces made the clipping scale -- and with it every parameter of a clipped step -- differ in the last bit from
+// run to run.  The partial buffer is a per-device symbol: calls are expected on one stream at a time (the optimiser's).
+constexpr int SUMSQ_MAX_BLOCKS = 4096;
+__device__ float g_sumsq_part[SUMSQ_MAX_BLOCKS];
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n) {
     __shared__ float red[4];
     float s = 0.f;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) g_sumsq_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_finalize_kernel(int nblk, float* out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += g_sumsq_part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out += red[0];
 }
 
 inline int grid_for(long long total, int per_thread = 4) {
@@ -1697,8 +1716,12 @@ int msseg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
 
 int msseg_sumsq(const float* x, long long n, float* out, msseg_stream_t stream) {
     if (!x || !out || n < 1) MSSEG_FAIL(MSSEG_EINVAL, "sumsq: bad args");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 16)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    int nblk = grid_for(n, 16);
+    if (nblk > SUMSQ_MAX_BLOCKS) nblk = SUMSQ_MAX_BLOCKS;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, n);
     MSSEG_CHECK_LAUNCH("sumsq");
+    hipLaunchKernelGGL(sumsq_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nblk, out);   // *out += the sum
+    MSSEG_CHECK_LAUNCH("sumsq_finalize");
     return MSSEG_OK;
 }
 

@@ -452,3 +452,32 @@ def test_unet_inference_split_concat_equals_concat_buffer(monkeypatch):
     agree = float((a.argmax(-1) == b.argmax(-1)).float().mean())
     print(f"infer_cl split-concat vs concat buffer: max diff / scale {d:.2e}, arg-max agreement {agree:.4f}")
     assert d < 2e-2 and agree > 0.99
+
+
+def test_unet_inference_8_windows_ksplit_and_stem_unit_vs_plain_forms(monkeypatch):
+    """UNet.infer_cl on a batch of 8 windows (the sliding-window launch shape): the 24^3-level 64- / 128-input-channel convs as 2 / 4
+    launches of the 32-channel ping-pong kernel and the one-channel stem unit as statistics-only launch + normalising conv, against the
+    forms they replace (MSSEG_NO_KSPLIT_INFER=1, MSSEG_NO_STEM_TWICE=1): bf16 logits agree to the extra rounding of the
+    intermediate sums, the arg-max almost everywhere"""
+    from medicalsemseg_amd import hip
+    _, net = _unet_pair(torch.bfloat16)
+    g = torch.Generator().manual_seed(4)
+    win = torch.randn(8, 96, 96, 96, 1, generator=g).to(DEV).to(torch.bfloat16)
+    hip.TIMER.records.clear()
+    hip.TIMER.enabled = True
+    try:
+        a = net.infer_cl(win)[..., :3].float()
+        torch.cuda.synchronize()
+    finally:
+        hip.TIMER.enabled = False
+    summ = hip.TIMER.summary()
+    hip.TIMER.records.clear()
+    assert summ.get("conv3d_k3_fwd/v1", {}).get("launches", 0) == 0      # nothing of the 24^3 level on the generic 4x4x8 kernel
+    assert summ.get("conv3d_stem_norm_fwd", {}).get("launches", 0) == 1
+    monkeypatch.setenv("MSSEG_NO_KSPLIT_INFER", "1")
+    monkeypatch.setenv("MSSEG_NO_STEM_TWICE", "1")
+    b = net.infer_cl(win)[..., :3].float()
+    d = float((a - b).abs().max()) / float(b.abs().max())
+    agree = float((a.argmax(-1) == b.argmax(-1)).float().mean())
+    print(f"infer_cl, 8 windows: K-split + two-launch stem vs plain forms: max diff / scale {d:.2e}, arg-max agreement {agree:.4f}")
+    assert d < 2.5e-2 and agree > 0.99

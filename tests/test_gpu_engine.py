@@ -183,6 +183,46 @@ def test_two_phase_backward_equals_single_phase(dtype):
     assert torch.equal(opt.flat_grad, ref)
 
 
+def test_lazy_zero_grad_equals_zero_filled_gradients(monkeypatch):
+    """FlatAdamW.zero_grad() without the fill (the first kernel that writes a gradient in an epoch overwrites it) against the
+    zero-filled buffer with accumulating kernels (MSSEG_EAGER_ZERO_GRAD=1): the same parameters bit for bit after three
+    clipped steps -- with a torch-autograd-written parameter in the optimiser (its slice keeps the fill), with a parameter no
+    kernel touches in the second step, and with two backward passes before one of the steps (gradient accumulation)"""
+    from medicalsemseg_amd.losses import DiceCELoss
+    from medicalsemseg_amd.models.unet import UNET_FEATURES, UNet
+    from medicalsemseg_amd.optim import FlatAdamW, add_weight_decay
+
+    def run(eager):
+        if eager:
+            monkeypatch.setenv("MSSEG_EAGER_ZERO_GRAD", "1")
+        else:
+            monkeypatch.delenv("MSSEG_EAGER_ZERO_GRAD", raising=False)
+        torch.manual_seed(5)
+        net = UNet(1, 2, UNET_FEATURES["UNetSmall"], compute_dtype=torch.bfloat16).to(DEV)
+        extra = torch.nn.Parameter(torch.full((3,), 0.5, device=DEV))           # written by torch autograd only
+        unused = torch.nn.Parameter(torch.full((5,), 0.25, device=DEV))         # written in the first step only
+        groups = add_weight_decay(net, 1e-5)
+        groups[0]["params"] += [extra, unused]
+        opt = FlatAdamW(groups, lr=1e-3)
+        crit = DiceCELoss()
+        g = torch.Generator().manual_seed(9)
+        for it in range(3):
+            for rep in range(2 if it == 1 else 1):                                  # step 1 accumulates two backward passes
+                x = torch.randn(2, 1, 32, 32, 32, generator=g).to(DEV)
+                y = torch.randint(0, 2, (2, 1, 32, 32, 32), generator=g).float().to(DEV)
+                loss = crit(net((x, None, None)), y) + (extra * extra).sum() * 0.1
+                if it == 0:
+                    loss = loss + (unused * unused).sum()
+                loss.backward()
+            opt.clip_grad_norm_(1.0)
+            opt.step()
+            opt.zero_grad()
+        return opt.flat_param.clone()
+
+    lazy, eager = run(False), run(True)
+    assert torch.equal(lazy, eager)
+
+
 def test_run_training_driver_synthetic(tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, "run_training.py"), "--synthetic", "--model", "UNetSmall", "--output_dim", "2",
            "--vol_size", "32", "--n_images_per_batch", "2", "--synthetic_steps", "3", "--epochs", "2", "--val_interval", "2",
