@@ -1189,15 +1189,24 @@ __global__ __launch_bounds__(256) void conv1x1_head_norm_kernel(const T* __restr
 #pragma unroll
         for (int c = 0; c < COUT; ++c) acc[c] = b[c];
         const T* xr = xn + v * ldx;
-        for (int k0 = 0; k0 < Cin; k0 += WD) {
-            Chunk<T> xc; xc.load(xr + k0);
+        // the row in pieces of up to four chunks, all loads of a piece issued before the first use (as conv1x1_head_kernel)
+        for (int k0 = 0; k0 < Cin; k0 += 4 * WD) {
+            Chunk<T> xc[4];
 #pragma unroll
-            for (int e = 0; e < WD; ++e) {
-                const float z = xc.v[e] * scS[k0 + e] + shS[k0 + e];
-                const float a = (float)(T)(z > 0.f ? z : z * slope);
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j * WD < Cin) xc[j].load(xr + k0 + j * WD);
 #pragma unroll
-                for (int c = 0; c < COUT; ++c) acc[c] += a * wS[c * Cin + k0 + e];
-            }
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j * WD < Cin) {
+#pragma unroll
+                    for (int e = 0; e < WD; ++e) {
+                        const int k = k0 + j * WD + e;
+                        const float z = xc[j].v[e] * scS[k] + shS[k];
+                        const float a = (float)(T)(z > 0.f ? z : z * slope);
+#pragma unroll
+                        for (int c = 0; c < COUT; ++c) acc[c] += a * wS[c * Cin + k];
+                    }
+                }
         }
         T* yr = yn + v * ldy;
 #pragma unroll
