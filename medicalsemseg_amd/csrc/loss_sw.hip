@@ -15,6 +15,25 @@ MSSEG_DEVFN int load_label(const void* labels, int label_dtype, long long idx) {
     }
 }
 
+// a 16-byte logits row (channels-last, ld * sizeof(T) == 16, what the networks' logits buffers are): ONE vector load per
+// voxel instead of one 2-byte load per class
+template <typename T, int CMAX>
+MSSEG_DEVFN void unpack_row(const u32x4_t raw, int C, float* x) {
+    constexpr int EPC = DT<T>::EPC;
+    float v[EPC];
+    if constexpr (sizeof(T) == 2) {
+        const bf16x8_t h = __builtin_bit_cast(bf16x8_t, raw);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = (float)h[e];
+    } else {
+        const f32x4_t f = __builtin_bit_cast(f32x4_t, raw);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = f[e];
+    }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) x[c] = (c < C && c < EPC) ? v[c < EPC ? c : 0] : -INFINITY;
+}
+
 template <typename T, int CMAX>
 MSSEG_DEVFN void load_logits(const T* base, long long ld, long long S, int C, long long n, long long s, float* x) {
     // ld > 0: channels-last [N][S][ld]; ld == 0: NCDHW [N][C][S]
@@ -57,9 +76,10 @@ __global__ __launch_bounds__(256) void dice_ce_partials_kernel(const T* __restri
     for (int c = 0; c < CMAX; ++c)
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc[c][k] = 0.f;
-    for (long long s = s0 + threadIdx.x; s < s1; s += 256) {
-        float x[CMAX];
-        load_logits<T, CMAX>(logits, ld, S, C, n, s, x);
+    // four voxels per trip, their rows and labels requested before the first is used (a loop of one voxel per trip kept a
+    // single 2-byte load in flight per class: 1.3 TB/s); the per-thread order of the voxels, and with it every sum, is unchanged
+    const bool vec = ld > 0 && ld * (long long)sizeof(T) == 16 && C <= DT<T>::EPC && (((uintptr_t)logits) & 15) == 0;
+    auto one = [&](float* x, int lab) {
         int am = 0;
         float best = x[0];
 #pragma unroll
@@ -70,7 +90,6 @@ __global__ __launch_bounds__(256) void dice_ce_partials_kernel(const T* __restri
         for (int c = 0; c < CMAX; ++c) raw[c] = x[c];
         float lse;
         softmax_inplace<CMAX>(x, C, lse);
-        const int lab = load_label(labels, label_dtype, n * S + s);
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
             if (c < C) {
@@ -83,6 +102,40 @@ __global__ __launch_bounds__(256) void dice_ce_partials_kernel(const T* __restri
                 acc[c][4] += pm * t;
                 acc[c][5] += pm;
                 acc[c][6] += t;
+            }
+        }
+    };
+    for (long long s = s0 + threadIdx.x; s < s1; s += 1024) {
+        if (vec) {
+            u32x4_t rows4[4];
+            int lab4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long sj = s + 256 * j;
+                rows4[j] = u32x4_t{0u, 0u, 0u, 0u};
+                lab4[j] = 0;
+                if (sj < s1) {
+                    rows4[j] = *(const u32x4_t*)(logits + (n * S + sj) * ld);
+                    lab4[j] = load_label(labels, label_dtype, n * S + sj);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (s + 256 * j < s1) {
+                    float x[CMAX];
+                    unpack_row<T, CMAX>(rows4[j], C, x);
+                    one(x, lab4[j]);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const long long sj = s + 256 * j;
+                if (sj < s1) {
+                    float x[CMAX];
+                    load_logits<T, CMAX>(logits, ld, S, C, n, sj, x);
+                    one(x, load_label(labels, label_dtype, n * S + sj));
+                }
             }
         }
     }
@@ -206,12 +259,11 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const T* __restrict__ 
             kb[c] = 2.f * num / (den * den) * wd;  // multiplies p
         }
     }
-    for (long long s = blockIdx.x * 256LL + threadIdx.x; s < S; s += (long long)gridDim.x * 256) {
-        float x[CMAX];
-        load_logits<T, CMAX>(logits, ld, S, C, n, s, x);
+    const bool vec = ld > 0 && ld * (long long)sizeof(T) == 16 && ldd == ld && C <= DT<T>::EPC &&
+                     ((((uintptr_t)logits) | ((uintptr_t)dlogits)) & 15) == 0;
+    auto grad = [&](float* x, int lab, float* d) {   // x: logits in, probabilities out; d[c] = d loss / d logit c
         float lse;
         softmax_inplace<CMAX>(x, C, lse);
-        const int lab = load_label(labels, label_dtype, n * S + s);
         float g[CMAX], dot = 0.f;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
@@ -221,11 +273,63 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const T* __restrict__ 
         }
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
+            const float t = (lab == c) ? 1.f : 0.f;
+            d[c] = (c < C) ? x[c] * (g[c] - dot) + wc * (x[c] - t) : 0.f;
+        }
+    };
+    const long long stride = (long long)gridDim.x * 256;
+    if (vec) {
+        // 16-byte rows in and out: one vector load and ONE vector store per voxel (the padding channels are written as zeros
+        // in the same store), four voxels per trip with all loads first
+        constexpr int EPC = DT<T>::EPC;
+        for (long long s = blockIdx.x * 256LL + threadIdx.x; s < S; s += 4 * stride) {
+            u32x4_t rows4[4];
+            int lab4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long sj = s + j * stride;
+                rows4[j] = u32x4_t{0u, 0u, 0u, 0u};
+                lab4[j] = 0;
+                if (sj < S) {
+                    rows4[j] = *(const u32x4_t*)(logits + (n * S + sj) * ld);
+                    lab4[j] = load_label(labels, label_dtype, n * S + sj);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long sj = s + j * stride;
+                if (sj < S) {
+                    float x[CMAX], d[CMAX];
+                    unpack_row<T, CMAX>(rows4[j], C, x);
+                    grad(x, lab4[j], d);
+                    u32x4_t o;
+                    if constexpr (sizeof(T) == 2) {
+                        bf16x8_t h;
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) h[e] = (bf16_t)((e < CMAX && e < C) ? d[e < CMAX ? e : 0] : 0.f);
+                        o = __builtin_bit_cast(u32x4_t, h);
+                    } else {
+                        f32x4_t f;
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) f[e] = (e < CMAX && e < C) ? d[e < CMAX ? e : 0] : 0.f;
+                        o = __builtin_bit_cast(u32x4_t, f);
+                    }
+                    *(u32x4_t*)(dlogits + (n * S + sj) * ldd) = o;
+                }
+            }
+        }
+        return;
+    }
+    for (long long s = blockIdx.x * 256LL + threadIdx.x; s < S; s += stride) {
+        float x[CMAX], d[CMAX];
+        load_logits<T, CMAX>(logits, ld, S, C, n, s, x);
+        const int lab = load_label(labels, label_dtype, n * S + s);
+        grad(x, lab, d);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
             if (c < C) {
-                const float t = (lab == c) ? 1.f : 0.f;
-                const float d = x[c] * (g[c] - dot) + wc * (x[c] - t);
-                if (ldd > 0) DT<T>::st(dlogits + (n * S + s) * ldd + c, d);
-                else DT<T>::st(dlogits + (n * C + c) * S + s, d);
+                if (ldd > 0) DT<T>::st(dlogits + (n * S + s) * ldd + c, d[c]);
+                else DT<T>::st(dlogits + (n * C + c) * S + s, d[c]);
             }
         }
         if (ldd > C) {
