@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256) void sw_blend_batch_kernel(const T* __restrict
     for (int i = threadIdx.x; i < nwin * 4; i += 256) tab[i] = table[i];
     __syncthreads();
     const long long R = (long long)RD * RH * RW, V = (long long)VD * VH * VW;
+    const bool vecw = ldw > 0 && ldw * (long long)sizeof(T) == 16 && C <= DT<T>::EPC && (((uintptr_t)win) & 15) == 0;
     const int j = blockIdx.y;
     const int b = tab[j * 4 + 0];
     if (b < 0) return;
@@ -452,12 +453,19 @@ __global__ __launch_bounds__(256) void sw_blend_batch_kernel(const T* __restrict
             if (dz >= (unsigned)RD || dy >= (unsigned)RH || dx >= (unsigned)RW) continue;
             const long long pi = ((long long)dz * RH + dy) * RW + dx;
             const float w = imp[pi];
+            float vals[CMAX];
+            if (vecw) {   // 16-byte logits rows (the networks' channels-last logits): one load per (voxel, window)
+                unpack_row<T, CMAX>(*(const u32x4_t*)(win + ((long long)k * R + pi) * ldw), C, vals);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    vals[c] = c < C ? (ldw > 0 ? DT<T>::ld(win + ((long long)k * R + pi) * ldw + c)
+                                               : DT<T>::ld(win + ((long long)k * C + c) * R + pi)) : 0.f;
+            }
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) {
                 if (c < C) {
-                    const float val = ldw > 0 ? DT<T>::ld(win + ((long long)k * R + pi) * ldw + c)
-                                              : DT<T>::ld(win + ((long long)k * C + c) * R + pi);
-                    const float prod = w * val;
+                    const float prod = w * vals[c];
                     o[c] = o[c] + prod;
                 }
             }
