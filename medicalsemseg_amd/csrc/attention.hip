@@ -457,9 +457,26 @@ template <typename T, bool BWD> bool launch_ln_vec(LnVecParams p, hipStream_t st
     return true;
 }
 
+// exact-erf GELU (nn.GELU of the patch merging, swin_nnformer.py:306) and its gradient; 16-byte chunks where the tensors are
+// aligned (one element per thread and trip ran at a fraction of the memory rate), the scalar form for the rest
 template <typename T, bool BWD>
 __global__ void gelu_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, long long n) {
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    constexpr int EPC = DT<T>::EPC;
+    const bool vec = ((((uintptr_t)x) | ((uintptr_t)out) | (BWD ? (uintptr_t)dy : 0)) & 15) == 0;
+    const long long nvec = vec ? n / EPC : 0;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        float v[EPC], g[EPC], o[EPC];
+        ln_load<T>(x + i * EPC, v);
+        if constexpr (BWD) ln_load<T>(dy + i * EPC, g);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float cdf = 0.5f * (1.f + erff(v[e] * 0.70710678118654752f));
+            if constexpr (!BWD) o[e] = v[e] * cdf;
+            else o[e] = g[e] * (cdf + v[e] * 0.3989422804014327f * expf(-0.5f * v[e] * v[e]));
+        }
+        ln_store<T>(out + i * EPC, o);
+    }
+    for (long long i = nvec * EPC + blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float v = DT<T>::ld(x + i);
         const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
         if constexpr (!BWD) DT<T>::st(out + i, v * cdf);
