@@ -2,7 +2,8 @@
 //
 //   dW[co][tap][ci] = sum_v dy[v][co] * x[v + tap][ci]
 //
-// (torch.nn.Conv3d weight gradient of the MONAI Convolution blocks built at /root/reference/models/model_builder.py:46-58.)
+// (torch.nn.Conv3d weight gradient of MONAI's Convolution blocks: BasicUNet's TwoConv -- BASELINE.json configs 1-3, SURVEY.md row A15;
+// MONAI is not vendored by the reference -- and the UnetResBlock convs built at /root/reference/models/segmentors/swin_unetr.py:73-128.)
 // Same execution scheme as conv3d_k3_pp.hip: one persistent workgroup of 8 waves per CU in two groups of 4 that
 // alternate roles per phase -- one group runs MFMAs on the tile staged in its LDS buffers, the other issues the
 // LDS-DMA loads (global_load_lds_dwordx4) of its next tile.  One workgroup grid column per (32-cout, 32-cin) block pair.

@@ -1,7 +1,8 @@
 // Stem convolution: conv3d 3x3x3 (stride 1, pad 1) with ONE input channel, bf16, and its weight gradient.
 //
-// BasicUNet's first layer (conv_0.conv_0: 1 -> 32 channels at full resolution; MONAI TwoConv built at
-// /root/reference/models/model_builder.py:46-58) has K = 27: it writes 113 MB per 96^3 batch-2 step for 1.5 GFLOP,
+// BasicUNet's first layer (conv_0.conv_0: 1 -> 32 channels at full resolution; MONAI TwoConv -- BASELINE.json configs 1-3,
+// SURVEY.md row A15; MONAI is not vendored by the reference) and the first conv of Swin-UNETR's encoder1 UnetResBlock
+// (/root/reference/models/segmentors/swin_unetr.py:73-81: 1 -> 48) have K = 27: it writes 113 MB per 96^3 batch-2 step for 1.5 GFLOP,
 // i.e. it is bound by its output stream, and its weight gradient by reading the output gradient once.  On the
 // generic gather path every operand element was a separate global load (224 us + 98 us); here the one-channel halo
 // lives in LDS and the taps are gathered from it.
