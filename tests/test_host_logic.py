@@ -394,3 +394,34 @@ def test_nifti_writer_round_trip_and_header(tmp_path):
     save_nifti(str(tmp_path / "img.nii.gz"), vol, np.eye(4))
     back, _ = load_nifti(str(tmp_path / "img.nii.gz"))
     assert back.dtype == np.float32 and np.array_equal(back, vol)
+
+
+def test_grad_buffer_epochs_and_sub_grid_word():
+    """host logic of the lazy gradient buffers (layers._grad_buf: who overwrites, who accumulates) and of the packed sub-grid word
+    of the PatchMerging gather (hip.merge_subs) -- no kernel involved"""
+    import torch
+    from medicalsemseg_amd import hip, layers
+
+    class Owner:                       # what optim.FlatAdamW exposes to _grad_buf
+        _gepoch = 0
+
+    o = Owner()
+    p = torch.nn.Parameter(torch.zeros(3))
+    # no gradient yet: a fresh buffer, overwrite
+    g, acc = layers._grad_buf(p)
+    assert acc is False and g is p.grad
+    # ordinary optimiser (no owner): always accumulate into the existing buffer
+    assert layers._grad_buf(p)[1] is True and layers._grad_buf(p)[1] is True
+    # owned, first kernel write ever: the slice was zero-filled this epoch, accumulate; the parameter becomes kernel-written
+    p._msseg_gowner, p._msseg_gepoch = o, -1
+    assert layers._grad_buf(p)[1] is True and p._msseg_kgrad is True and p._msseg_gepoch == 0
+    assert layers._grad_buf(p)[1] is True                     # a second writer in the same epoch adds
+    o._gepoch = 1                                             # zero_grad(): a new epoch, nothing filled
+    assert layers._grad_buf(p)[1] is False                    # first writer overwrites
+    assert layers._grad_buf(p)[1] is True                     # later writers (gradient accumulation, shared weights) add
+    o._gepoch = 2
+    assert layers._grad_buf(p)[1] is False
+    # the reference's sub-grid order with its duplicates: (a, b, c) -> a | b << 1 | c << 2, slot s at bits 3s..3s+2
+    sub = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 0), (0, 0, 1), (1, 1, 1)]
+    word = hip.merge_subs(sub)
+    assert [(word >> (3 * s)) & 7 for s in range(8)] == [0, 1, 2, 4, 5, 2, 4, 7]
