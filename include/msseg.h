@@ -72,7 +72,9 @@ typedef struct msseg_pack_job {
     long long total;          /* elements of the destination image = msseg_packed_weight_bytes / element size */
     int M, M0, T, K, K0, flip, cout_block, nkb;   /* nkb = ceil(K / (64 / element size)) */
 } msseg_pack_job;
-int msseg_pack_weights_batch(const msseg_pack_job* jobs_dev, int njobs, long long max_total, int dtype,
+/* max_total / sum_total: largest and summed `total` of the table's jobs (the table itself is device memory: the grid is sized
+ * from these) */
+int msseg_pack_weights_batch(const msseg_pack_job* jobs_dev, int njobs, long long max_total, long long sum_total, int dtype,
                              msseg_stream_t stream);
 /* cout block (16/32/48) the igemm kernels use for a layer with M logical output channels */
 int msseg_cout_block(int M);
@@ -502,8 +504,10 @@ int msseg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      const float* grad_scale, const float* dev_hyper /* nullable: device [lr, step] overriding the
                      host values, so a captured hipGraph can be replayed while the schedule advances */,
                      msseg_stream_t stream);
-/* out[0] = sum of squares of x[0..n) (caller zero-fills out). */
-int msseg_sumsq(const float* x, long long n, float* out, msseg_stream_t stream);
+/* out[0] = sum of squares of x[0..n), added in a fixed order (bit-identical from run to run): per-block sums into
+   partials[0..n_partials) -- a buffer of the caller, at most n_partials blocks are launched (4096 is plenty) -- then one
+   block adds them and overwrites out[0]. */
+int msseg_sumsq(const float* x, long long n, float* out, float* partials, int n_partials, msseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sliding-window inference (engine/utils.py:120-151): gather windows, weighted blend, normalise.

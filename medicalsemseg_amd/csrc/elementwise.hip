@@ -1081,37 +1081,84 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict
     }
 }
 
+// All images of a network in one launch.  Flat grid: block b belongs to the job whose run of ceil(chunks / PACK_CPB) blocks
+// contains b (the first wave finds it with a prefix sum over the table), so a table of many small and a few large images
+// fills the chip evenly (a grid of [blocks of the largest image] x [jobs] left most blocks empty and the largest image on ~100 of
+// them: 56 us for the UNet's 23 MB, 0.8 TB/s).  One thread packs PACK_CPT 16-byte chunks, all their source loads in flight together.
+constexpr unsigned PACK_CPT = 4, PACK_CPB = 256 * PACK_CPT;
+
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const msseg_pack_job* __restrict__ jobs) {
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const msseg_pack_job* __restrict__ jobs, int njobs) {
     constexpr unsigned EPC = DT<T>::EPC;
-    const msseg_pack_job j = jobs[blockIdx.y];
+    __shared__ int sel[2];
+    if (threadIdx.x < 64) {
+        const unsigned lane = threadIdx.x;
+        if (lane == 0) sel[0] = -1;
+        unsigned before = 0;
+        for (int base = 0; base < njobs; base += 64) {   // wave-uniform trip count and exit
+            const int jj = base + (int)lane;
+            const unsigned nb = jj < njobs ? (unsigned)((jobs[jj].total / EPC + PACK_CPB - 1) / PACK_CPB) : 0u;
+            unsigned incl = nb;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = __shfl_up(incl, o);
+                if ((int)lane >= o) incl += v;
+            }
+            const unsigned lo = before + incl - nb;
+            const bool mine = blockIdx.x >= lo && blockIdx.x < lo + nb;
+            if (mine) { sel[0] = jj; sel[1] = (int)(blockIdx.x - lo); }
+            if (__ballot(mine)) break;
+            before += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+    if (sel[0] < 0) return;            // a block past the last job's run (the host rounds the grid up)
+    const msseg_pack_job j = jobs[sel[0]];
     T* dst = (T*)j.dst;
-    // 32-bit index arithmetic (images are far below 2^31 elements); one thread packs one 16-byte chunk
+    // 32-bit index arithmetic (images are far below 2^31 elements)
     const unsigned nchunks = (unsigned)(j.total / EPC), cb_w = (unsigned)j.cout_block, Tt = (unsigned)j.T, nkb = (unsigned)j.nkb;
-    // work order: tap fastest, so that neighbouring threads read neighbouring source elements of a conv weight
-    // ([m][k][tap] in torch layout: the 8 k x T taps of a chunk group are one contiguous run); the destination chunk
-    // index is recomputed from the coordinates
-    for (unsigned wi = blockIdx.x * 256u + threadIdx.x; wi < nchunks; wi += gridDim.x * 256u) {
+    // work order: eight neighbouring columns fastest (eight lanes fill one 128-byte line of the image), then the taps (neighbouring
+    // source elements of a conv weight, [m][k][tap] in torch layout), then the other columns; the destination chunk index is
+    // recomputed from the coordinates
+    const unsigned cb8 = cb_w >> 3;
+    float v[PACK_CPT][EPC];
+    unsigned ch[PACK_CPT];
+#pragma unroll
+    for (unsigned i = 0; i < PACK_CPT; ++i) {
+        const unsigned wi = (unsigned)sel[1] * PACK_CPB + i * 256u + threadIdx.x;
+        ch[i] = 0xffffffffu;
+#pragma unroll
+        for (unsigned e = 0; e < EPC; ++e) v[i][e] = 0.f;
+        if (wi >= nchunks) continue;
         unsigned t = wi;
+        const unsigned col_lo = t & 7u; t >>= 3;
         const unsigned tap = t % Tt; t /= Tt;
-        const unsigned col = t % cb_w; t /= cb_w;
+        const unsigned col = (t % cb8) * 8u + col_lo; t /= cb8;
         const unsigned q = t & 3u; t >>= 2;
         const unsigned kb = t % nkb;
         const unsigned cb = t / nkb;
-        const unsigned ch = (((cb * nkb + kb) * Tt + tap) * 4u + q) * cb_w + col;
+        ch[i] = (((cb * nkb + kb) * Tt + tap) * 4u + q) * cb_w + col;
         const int m = (int)(cb * cb_w + col);
+        if (m >= j.M) continue;
         const unsigned tt = j.flip ? (Tt - 1 - tap) : tap;
-        alignas(16) T out[EPC];
-        const bool mok = m < j.M;
-        const long long mbase = mok ? (long long)(m / j.M0) * j.s_m1 + (long long)(m % j.M0) * j.s_m0 + (long long)tt * j.s_t : 0;
+        const long long mbase = (long long)(m / j.M0) * j.s_m1 + (long long)(m % j.M0) * j.s_m0 + (long long)tt * j.s_t;
+        // k = k1 * K0 + k0 of the chunk's first element by one division, the other seven by carry (16 runtime divisions per chunk
+        // made this pass instruction-bound)
+        const int kfirst = (int)(kb * 4 * EPC + q * EPC);
+        int k1 = kfirst / j.K0, k0 = kfirst - k1 * j.K0;
 #pragma unroll
         for (unsigned e = 0; e < EPC; ++e) {
-            const int k = (int)(kb * 4 * EPC + q * EPC + e);
-            float v = 0.f;
-            if (mok && k < j.K) v = j.src[mbase + (long long)(k / j.K0) * j.s_k1 + (long long)(k % j.K0) * j.s_k0];
-            DT<T>::st(&out[e], v);
+            if (kfirst + (int)e < j.K) v[i][e] = j.src[mbase + (long long)k1 * j.s_k1 + (long long)k0 * j.s_k0];
+            if (++k0 == j.K0) { k0 = 0; ++k1; }
         }
-        *(u32x4_t*)(dst + (size_t)ch * EPC) = *(const u32x4_t*)out;
+    }
+#pragma unroll
+    for (unsigned i = 0; i < PACK_CPT; ++i) {
+        if (ch[i] == 0xffffffffu) continue;
+        alignas(16) T out[EPC];
+#pragma unroll
+        for (unsigned e = 0; e < EPC; ++e) DT<T>::st(&out[e], v[i][e]);
+        *(u32x4_t*)(dst + (size_t)ch[i] * EPC) = *(const u32x4_t*)out;
     }
 }
 
@@ -1260,31 +1307,28 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 // Sum of squares (the gradient norm of clip_grad_norm_) in a fixed order: per-block partials, then one block adds them.  The float
 // atomicAdd this replaces made the clipping scale -- and with it every parameter of a clipped step -- differ in the last bit from
-// run to run.  The partial buffer is a per-device symbol: calls are expected on one stream at a time (the optimiser's).
-constexpr int SUMSQ_MAX_BLOCKS = 4096;
-__device__ float g_sumsq_part[SUMSQ_MAX_BLOCKS];
-
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n) {
+// run to run.  The partial rows live in a buffer of the caller (nothing here is shared between calls).
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
     __shared__ float red[4];
     float s = 0.f;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) g_sumsq_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void sumsq_finalize_kernel(int nblk, float* out) {
+__global__ __launch_bounds__(256) void sumsq_finalize_kernel(const float* __restrict__ part, int nblk, float* out) {
     __shared__ float red[256];
     float s = 0.f;
-    for (int i = threadIdx.x; i < nblk; i += 256) s += g_sumsq_part[i];
+    for (int i = threadIdx.x; i < nblk; i += 256) s += part[i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out += red[0];
+    if (threadIdx.x == 0) *out = red[0];
 }
 
 inline int grid_for(long long total, int per_thread = 4) {
@@ -1329,18 +1373,18 @@ int msseg_pack_weights(const float* src, void* dst, int dtype, int M, int M0, in
     return MSSEG_OK;
 }
 
-int msseg_pack_weights_batch(const msseg_pack_job* jobs_dev, int njobs, long long max_total, int dtype,
+int msseg_pack_weights_batch(const msseg_pack_job* jobs_dev, int njobs, long long max_total, long long sum_total, int dtype,
                              msseg_stream_t stream) {
-    if (!jobs_dev || njobs < 1 || njobs > 65535 || max_total < 1) MSSEG_FAIL(MSSEG_EINVAL, "pack_weights_batch: bad args");
-    // blocks per job sized by the largest image (16 chunks of 16 B per thread); smaller jobs leave their extra blocks
-    // idle.  The cap keeps the grid of a many-job table small: the 64 MB conv weights of Swin-UNETR's deep stages want
-    // hundreds of blocks, the UNet's largest (7 MB) about fifty.
-    long long gx = ceil_div_ll(max_total, 256LL * 8 * 16);
-    if (gx > 512) gx = 512;
-    if (gx < 1) gx = 1;
-    dim3 grid((unsigned)gx, (unsigned)njobs);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev),
-               hipLaunchKernelGGL(pack_weights_batch_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev));
+    if (!jobs_dev || njobs < 1 || njobs > 65535 || max_total < 1 || sum_total < max_total)
+        MSSEG_FAIL(MSSEG_EINVAL, "pack_weights_batch: bad args");
+    const long long epc = dtype == MSSEG_F32 ? 4 : 8;
+    if (max_total / epc >= 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "pack_weights_batch: image too large");
+    // sum over the jobs of ceil(chunks / PACK_CPB) <= sum of chunks / PACK_CPB + njobs: the blocks past the end find no job and exit
+    const long long gx = sum_total / epc / PACK_CPB + njobs + 1;
+    if (gx >= 0x7fffffffLL) MSSEG_FAIL(MSSEG_EINVAL, "pack_weights_batch: too many blocks");
+    dim3 grid((unsigned)gx);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weights_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs),
+               hipLaunchKernelGGL(pack_weights_batch_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs));
     MSSEG_CHECK_LAUNCH("pack_weights_batch");
     return MSSEG_OK;
 }
@@ -1723,13 +1767,13 @@ int msseg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
     return MSSEG_OK;
 }
 
-int msseg_sumsq(const float* x, long long n, float* out, msseg_stream_t stream) {
-    if (!x || !out || n < 1) MSSEG_FAIL(MSSEG_EINVAL, "sumsq: bad args");
+int msseg_sumsq(const float* x, long long n, float* out, float* partials, int n_partials, msseg_stream_t stream) {
+    if (!x || !out || !partials || n < 1 || n_partials < 1) MSSEG_FAIL(MSSEG_EINVAL, "sumsq: bad args");
     int nblk = grid_for(n, 16);
-    if (nblk > SUMSQ_MAX_BLOCKS) nblk = SUMSQ_MAX_BLOCKS;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, n);
+    if (nblk > n_partials) nblk = n_partials;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, n, partials);
     MSSEG_CHECK_LAUNCH("sumsq");
-    hipLaunchKernelGGL(sumsq_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nblk, out);   // *out += the sum
+    hipLaunchKernelGGL(sumsq_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, nblk, out);
     MSSEG_CHECK_LAUNCH("sumsq_finalize");
     return MSSEG_OK;
 }

@@ -29,7 +29,7 @@ SIGNATURES = {
     "msseg_num_cus": ([], _i),
     "msseg_packed_weight_bytes": ([_i, _i, _i, _i, _i], _sz),
     "msseg_pack_weights": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _i, _i, _vp], _i),
-    "msseg_pack_weights_batch": ([_vp, _i, _ll, _i, _vp], _i),
+    "msseg_pack_weights_batch": ([_vp, _i, _ll, _ll, _i, _vp], _i),
     "msseg_cout_block": ([_i], _i),
     "msseg_conv3d_k3_cout_block": ([_i, _i, _i, _i, _i], _i),
     "msseg_conv3d_k3_variant": ([_i, _i, _i, _i, _i], _i),
@@ -115,7 +115,7 @@ SIGNATURES = {
     "msseg_dice_ce_finalize": ([_vp, _vp, _i, _ll, _i, _f, _f, _vp], _i),
     "msseg_dice_ce_bwd": ([_vp, _ll, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, _ll, _i, _f, _f, _vp], _i),
     "msseg_adamw_step": ([_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp], _i),
-    "msseg_sumsq": ([_vp, _ll, _vp, _vp], _i),
+    "msseg_sumsq": ([_vp, _ll, _vp, _vp, _i, _vp], _i),
     "msseg_sw_blend": ([_vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "msseg_sw_normalize": ([_vp, _vp, _i, _ll, _vp], _i),
     "msseg_sw_gather": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp], _i),
@@ -282,9 +282,9 @@ def pack_weights(src: torch.Tensor, dtype: torch.dtype, M, M0, T, K, K0, s_m1, s
     return out
 
 
-def pack_weights_batch(table: torch.Tensor, njobs: int, max_total: int, dtype: torch.dtype):
-    """table: uint8 device tensor holding njobs consecutive PackJob structs"""
-    _ck(lib().msseg_pack_weights_batch(_p(table), njobs, max_total, _DT[dtype], _stream()), "pack_weights_batch")
+def pack_weights_batch(table: torch.Tensor, njobs: int, max_total: int, sum_total: int, dtype: torch.dtype):
+    """table: uint8 device tensor holding njobs consecutive PackJob structs; max_total / sum_total: largest / summed job.total"""
+    _ck(lib().msseg_pack_weights_batch(_p(table), njobs, max_total, sum_total, _DT[dtype], _stream()), "pack_weights_batch")
 
 
 def pack_conv_k3(w: torch.Tensor, dtype, dgrad=False, out=None, vol=None, cb=None):
@@ -1137,9 +1137,12 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, decay_mask, lr, beta1, beta2, e
         "adamw_step")
 
 
-def sumsq(x, out):
-    _need_gpu(x, out)
-    _ck(lib().msseg_sumsq(_p(x), x.numel(), _p(out), _stream()), "sumsq")
+def sumsq(x, out, partials):
+    """out[0] = sum of x^2 in a fixed order; `partials`: fp32 buffer of the caller for the per-block sums (overwritten)."""
+    _need_gpu(x, out, partials)
+    if partials.dtype != torch.float32 or not partials.is_contiguous():
+        raise ValueError("sumsq: partials must be a contiguous fp32 buffer")
+    _ck(lib().msseg_sumsq(_p(x), x.numel(), _p(out), _p(partials), partials.numel(), _stream()), "sumsq")
     return out
 
 

@@ -59,6 +59,7 @@ class _PackRegistry:
                 g["keep"].append(g["last"])   # a captured hipGraph may still reference the previous table
             g["table"] = g["last"] = host.to(device)
             g["max_total"] = max(int(r["job"].total) for r in jobs)
+            g["sum_total"] = sum(int(r["job"].total) for r in jobs)
 
     def prepare(self):
         """build every missing job table now (host-to-device copies are not allowed while a stream is capturing)"""
@@ -79,7 +80,7 @@ class _PackRegistry:
         g = self.groups[(device, dtype)]
         jobs = g["jobs"]
         self._ensure_table(g, device)
-        hip.pack_weights_batch(g["table"], len(jobs), g["max_total"], dtype)
+        hip.pack_weights_batch(g["table"], len(jobs), g["max_total"], g["sum_total"], dtype)
         for r in jobs:
             r["state"] = (r["src"]._version, weights_epoch)
 

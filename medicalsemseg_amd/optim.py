@@ -79,6 +79,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 p._msseg_gepoch = -1
         self._gscale = torch.ones(1, dtype=torch.float32, device=dev)
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._sq_part = torch.zeros(4096, dtype=torch.float32, device=dev)   # per-block sums of grad_norm (fixed-order reduction)
         # device-resident (lr, step): the fused kernel reads them, so a captured hipGraph replays correctly
         self._hyper = torch.tensor([lr, 0.0], dtype=torch.float32, device=dev)
         self._lr_on_device = lr
@@ -147,8 +148,7 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def grad_norm(self) -> torch.Tensor:
         self._zero_untouched()
-        self._sq.zero_()
-        hip.sumsq(self.flat_grad, self._sq)
+        hip.sumsq(self.flat_grad, self._sq, self._sq_part)
         return self._sq.sqrt()
 
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:

@@ -476,12 +476,19 @@ def test_batched_weight_packing_equals_single_packing():
     dev = _dev()
     ws = [torch.nn.Parameter(gen(*shape, seed=i).to(dev)) for i, shape in
           enumerate([(32, 32, 3, 3, 3), (64, 32, 3, 3, 3), (48, 96, 3, 3, 3), (3, 32, 1, 1, 1), (32, 1, 3, 3, 3),
-                     (48, 48, 3, 3, 3)])]     # the last one: the four-part image of the 48-channel kernel (bf16)
+                     (48, 48, 3, 3, 3),       # the four-part image of the 48-channel kernel (bf16)
+                     (64, 32, 3, 3, 3), (24, 40, 1, 1, 1), (64, 32, 2, 2, 2), (32, 24, 2, 2, 2), (32, 4, 3, 3, 3)])]
     for dtype in DTYPES:
         caches = [layers.PackedCache() for _ in ws]
         builders = [lambda w=w: hip.pack_conv_k3(w.detach(), dtype, vol=(2, 32, 32, 32)) for w in ws[:3]]
         builders += [lambda w=ws[3]: hip.pack_conv_k1(w.detach().reshape(3, 32), dtype), lambda w=ws[4]: hip.pack_conv_gather(w.detach(), dtype)]
         builders += [lambda w=ws[5]: hip.pack_conv_k3(w.detach(), dtype, vol=(2, 32, 32, 64))]
+        # input-gradient (flipped / transposed) images, ConvTranspose images (K = 8 * Cout in runs of K0 = Cout), a gather image
+        # with K0 = 4 (several carries inside one 16-byte chunk)
+        builders += [lambda w=ws[6]: hip.pack_conv_k3(w.detach(), dtype, dgrad=True, vol=(2, 32, 32, 32)),
+                     lambda w=ws[7]: hip.pack_conv_k1(w.detach().reshape(24, 40), dtype, dgrad=True),
+                     lambda w=ws[8]: hip.pack_deconv(w.detach(), dtype), lambda w=ws[9]: hip.pack_deconv(w.detach(), dtype, bwd=True),
+                     lambda w=ws[10]: hip.pack_conv_gather(w.detach(), dtype)]
         first = [c.get(w, dtype, "f", b).clone() for c, w, b in zip(caches, ws, builders)]
         with torch.no_grad():
             for w in ws:
